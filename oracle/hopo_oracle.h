@@ -1,0 +1,36 @@
+/* hopo_oracle.h -- TEST INFRASTRUCTURE ONLY (see hopo_oracle.c header). */
+#ifndef TATAJUBA_AMD_ORACLE_H
+#define TATAJUBA_AMD_ORACLE_H
+
+#include "../include/tatajuba_hopo.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct
+{
+  hopo_element *elem;
+  int n_elem, n_alloc, kmer_size, coverage, ref_start;
+  int *idx_initial, *idx_final, n_idx;
+  long n_reads;           /* reads seen by orc_scan_file / orc_scan_stream (bookkeeping only) */
+  long n_undefined;       /* qualifying non-ACGTU runs with no earlier tract in the read: reference reads
+                             uninitialised memory there (src/hopo_counter.c:223,248); the oracle emits nothing */
+  int status;             /* 0 ok; 1 = "no HTs before QC"; 2 = "none after filter"; 3 = "none reach min coverage" */
+} orc_counter;
+
+orc_counter *orc_new (int kmer_size);
+void orc_free (orc_counter *oc);
+void orc_scan_seq (orc_counter *oc, const char *seq, int seq_length, int min_tract_size);
+long orc_scan_file (orc_counter *oc, const char *path, int min_tract_size);        /* reads parsed, -1 = cannot open */
+long orc_scan_stream (orc_counter *oc, const char *buf, size_t n, int min_tract_size); /* '\n'-delimited reads */
+void orc_finalise (orc_counter *oc, int remove_biased, int min_coverage);
+int  orc_compare_decreasing (const void *a, const void *b);
+
+/* parser only: concatenates every parsed read followed by '\n' into a malloc'ed buffer (caller frees) */
+char *orc_parse_file_to_stream (const char *path, size_t *n_bytes, long *n_reads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

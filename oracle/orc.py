@@ -1,0 +1,138 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; nothing under
+tatajuba_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# numpy view of hopo_element (include/tatajuba_hopo.h; reference src/hopo_counter.h:34-49)
+ELEM_DTYPE = np.dtype([("ctx0", "<u8"), ("ctx1", "<u8"), ("meta", "<u8"), ("read_offset", "<i4"),
+                       ("loc_ref_id", "<i4"), ("loc_pos", "<i4"), ("loc_last", "<i4")])
+assert ELEM_DTYPE.itemsize == 40
+
+
+def _sx(v, bits):
+    """sign-extend the low `bits` bits of an int64 array"""
+    v = v.astype(np.int64) & ((1 << bits) - 1)
+    return np.where(v >= (1 << (bits - 1)), v - (1 << bits), v)
+
+
+def decode_meta(meta):
+    """bitfield word -> dict of signed fields (LSB-first layout, see tatajuba_hopo.h)"""
+    m = np.asarray(meta, dtype=np.uint64)
+    sh = lambda s: (m >> np.uint64(s))
+    return {"base": _sx(sh(0), 2), "length": _sx(sh(2), 10), "count": _sx(sh(12), 20),
+            "mismatches": _sx(sh(32), 12), "multi": _sx(sh(44), 3), "neg_strand": _sx(sh(47), 2),
+            "canon_flag": _sx(sh(49), 3)}
+
+
+class _OrcCounter(C.Structure):
+    _fields_ = [("elem", C.c_void_p), ("n_elem", C.c_int), ("n_alloc", C.c_int), ("kmer_size", C.c_int),
+                ("coverage", C.c_int), ("ref_start", C.c_int), ("idx_initial", C.POINTER(C.c_int)),
+                ("idx_final", C.POINTER(C.c_int)), ("n_idx", C.c_int), ("n_reads", C.c_long),
+                ("n_undefined", C.c_long), ("status", C.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    src = os.path.join(_HERE, "hopo_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liborc.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_new.restype = C.POINTER(_OrcCounter); L.orc_new.argtypes = [C.c_int]
+        L.orc_free.argtypes = [C.POINTER(_OrcCounter)]
+        L.orc_scan_seq.argtypes = [C.POINTER(_OrcCounter), C.c_char_p, C.c_int, C.c_int]
+        L.orc_scan_file.restype = C.c_long; L.orc_scan_file.argtypes = [C.POINTER(_OrcCounter), C.c_char_p, C.c_int]
+        L.orc_scan_stream.restype = C.c_long
+        L.orc_scan_stream.argtypes = [C.POINTER(_OrcCounter), C.c_void_p, C.c_size_t, C.c_int]
+        L.orc_finalise.argtypes = [C.POINTER(_OrcCounter), C.c_int, C.c_int]
+        L.orc_parse_file_to_stream.restype = C.c_void_p
+        L.orc_parse_file_to_stream.argtypes = [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
+        _LIB = L
+    return _LIB
+
+
+class Oracle:
+    """One sample's counter on the CPU oracle."""
+
+    def __init__(self, kmer_size):
+        self.k = kmer_size
+        self._p = lib().orc_new(kmer_size)
+
+    def close(self):
+        if self._p:
+            lib().orc_free(self._p)
+            self._p = None
+
+    __del__ = close
+
+    def scan_seq(self, seq, m):
+        if isinstance(seq, str):
+            seq = seq.encode("latin-1")
+        lib().orc_scan_seq(self._p, seq, len(seq), m)
+
+    def scan_file(self, path, m):
+        n = lib().orc_scan_file(self._p, os.fsencode(path), m)
+        if n < 0:
+            raise FileNotFoundError(path)
+        return n
+
+    def scan_stream(self, buf, m):
+        """buf: bytes / numpy uint8 array of '\\n'-terminated reads"""
+        a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+        a = np.ascontiguousarray(a)
+        return lib().orc_scan_stream(self._p, a.ctypes.data, a.size, m)
+
+    def finalise(self, remove_biased, min_coverage):
+        lib().orc_finalise(self._p, int(bool(remove_biased)), int(min_coverage))
+
+    # ---- views -------------------------------------------------------------------------------------------
+    @property
+    def c(self):
+        return self._p.contents
+
+    def elems(self):
+        n = self.c.n_elem
+        if n == 0:
+            return np.zeros(0, dtype=ELEM_DTYPE)
+        buf = (C.c_char * (n * 40)).from_address(self.c.elem)
+        return np.frombuffer(buf, dtype=ELEM_DTYPE).copy()
+
+    def idx(self):
+        n = self.c.n_idx
+        if n == 0 or not self.c.idx_initial:
+            return np.zeros(0, np.int32), np.zeros(0, np.int32)
+        return (np.ctypeslib.as_array(self.c.idx_initial, (n,)).copy(),
+                np.ctypeslib.as_array(self.c.idx_final, (n,)).copy())
+
+
+def parse_file_to_stream(path):
+    n = C.c_size_t(0)
+    r = C.c_long(0)
+    p = lib().orc_parse_file_to_stream(os.fsencode(path), C.byref(n), C.byref(r))
+    if not p:
+        raise FileNotFoundError(path)
+    out = np.frombuffer((C.c_char * n.value).from_address(p), dtype=np.uint8).copy() if n.value else np.zeros(0, np.uint8)
+    C.CDLL(None).free(C.c_void_p(p))
+    return out, r.value
+
+
+def name_of(ctx0, ctx1, base, k):
+    """left.base.right string (reference: generate_name_from_flanking_contexts, src/hopo_counter.c:471-493)"""
+    dna = "ACGT"
+    left = "".join(dna[(int(ctx0) >> (2 * i)) & 3] for i in range(k))
+    right = "".join(dna[(int(ctx1) >> (2 * i)) & 3] for i in range(k))
+    return f"{left}.{dna[int(base)]}.{right}"

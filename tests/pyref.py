@@ -1,0 +1,50 @@
+"""Independent pure-Python statement of the scan's CLOSED FORM, used to cross-check the
+C oracle on random strings.  Small inputs only.  Test infrastructure."""
+
+FWD = {c: v for c, v in zip("ACGTUacgtu", [0, 1, 2, 3, 3] * 2)}
+
+
+def code(ch, comp=False):
+    v = FWD.get(ch)
+    if v is None:
+        return 0            # non-ACGTU packs as 0 in either orientation (4 & 3)
+    return 3 - v if comp else v
+
+
+def pack(codes):
+    x = 0
+    for i, c in enumerate(codes):
+        x |= (c & 3) << (2 * i)
+    return x
+
+
+def scan_closed_form(seq, k, m):
+    """-> list of (base, length, read_offset, flag, ctx0, ctx1); seq is a str of single-byte chars.
+    A run [s,e] of identical bytes is recorded iff n >= max(m,2), s >= k, e + k <= L-1.  A qualifying run of a
+    non-ACGTU byte re-uses (ctx, base, flag) of the previous recorded ACGTU tract in the read, or is dropped when
+    there is none (undefined behaviour in the reference)."""
+    L = len(seq)
+    mm = max(m, 2)
+    out = []
+    last = None
+    s = 0
+    while s < L:
+        e = s
+        while e + 1 < L and seq[e + 1] == seq[s]:
+            e += 1
+        n = e - s + 1
+        if n >= mm and s >= k and e + k <= L - 1:
+            ch = seq[s]
+            if ch in FWD:
+                left = seq[s - k:s]
+                right = seq[e + 1:e + 1 + k]
+                f = FWD[ch]
+                if f < 2:
+                    last = (f, 1, pack([code(c) for c in left]), pack([code(c) for c in right]))
+                else:
+                    last = (3 - f, 2, pack([code(c, True) for c in reversed(right)]),
+                            pack([code(c, True) for c in reversed(left)]))
+            if last is not None:
+                out.append((last[0], n, s - k, last[1], last[2], last[3]))
+        s = e + 1
+    return out

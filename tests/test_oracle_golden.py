@@ -1,0 +1,167 @@
+"""The CPU oracle against every known-answer vector there is for this path (tests/golden/known_answers.json:
+the reference README's stored-name example and SURVEY.md 9.7's outputs of the unmodified reference), plus a
+cross-check of the C state machine against an independent closed-form statement on random strings."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.pyref import scan_closed_form
+
+
+def records_of(o, k):
+    e = o.elems()
+    d = orc.decode_meta(e["meta"])
+    return [(int(d["base"][i]), int(d["length"][i]), int(e["read_offset"][i]), int(d["canon_flag"][i]),
+             int(e["ctx0"][i]), int(e["ctx1"][i])) for i in range(len(e))]
+
+
+def test_scan_known_answers(known_answers):
+    for c in known_answers["scan"]:
+        o = orc.Oracle(c["k"])
+        o.scan_seq(c["seq"], c["m"])
+        got = records_of(o, c["k"])
+        exp = [(r[0], r[1], r[2], r[3], int(r[4], 16), int(r[5], 16)) for r in c["records"]]
+        assert got == exp, c["seq"]
+        for g, r in zip(got, c["records"]):
+            assert orc.name_of(g[4], g[5], g[0], c["k"]) == r[6]
+        e = o.elems()
+        d = orc.decode_meta(e["meta"])
+        assert (d["count"] == 1).all() and (d["mismatches"] == -2).all()
+        assert (d["multi"] == 0).all() and (d["neg_strand"] == 0).all()
+        assert (e["loc_ref_id"] == -1).all() and (e["loc_pos"] == -1).all() and (e["loc_last"] == -1).all()
+
+
+def test_readme_canonical_names(known_answers):
+    # README.md:226-230: CCG-A-GAT, its reverse strand and the C tract are stored as these three names
+    names = set()
+    for seq in ("TTCCGAAAAGATTT", "TTATCAAAACCGTT", "TTCCGCCCCGATTT"):
+        o = orc.Oracle(3)
+        o.scan_seq(seq, 3)
+        (r,) = [x for x in records_of(o, 3) if x[1] == 4]
+        names.add(orc.name_of(r[4], r[5], r[0], 3))
+    assert names == set(known_answers["readme"][0]["names_stored"])
+
+
+def test_stale_context_quirk(known_answers):
+    c0, c1 = known_answers["stale_context"]
+    o = orc.Oracle(c0["k"])
+    o.scan_seq(c0["seq"], c0["m"])
+    r = records_of(o, c0["k"])
+    assert len(r) == c0["n_records"]
+    assert (r[1][0], r[1][3], r[1][4], r[1][5]) == (r[0][0], r[0][3], r[0][4], r[0][5])
+    assert r[1][1] == c0["second_length"] and r[1][2] == c0["second_read_offset"]
+    o = orc.Oracle(c1["k"])
+    o.scan_seq(c1["seq"], c1["m"])
+    assert o.c.n_elem == c1["n_records_defined"] and o.c.n_undefined == 1
+
+
+def test_bitfield_wraps(known_answers):
+    b = known_answers["bitfields"]
+    meta = np.array([(512 & 0x3ff) << 2, (600 & 0x3ff) << 2, (524288 & 0xfffff) << 12, 0xffe << 32], dtype=np.uint64)
+    d = orc.decode_meta(meta)
+    assert d["length"][0] == b["length_512_reads_back"] and d["length"][1] == b["length_600_reads_back"]
+    assert d["count"][2] == b["count_524288_reads_back"] and d["mismatches"][3] == b["mismatches_0xffe_reads_back"]
+    # the oracle's own store wraps the same way
+    o = orc.Oracle(2)
+    o.scan_seq("AC" + "G" * 600 + "AC", 3)
+    assert records_of(o, 2)[0][1] == -424
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_file_aggregates(known_answers, golden_dir, case):
+    f = known_answers["file"]
+    c = f["cases"][case]
+    o = orc.Oracle(c["k"])
+    n = o.scan_file(os.path.join(golden_dir, f["path"]), c["m"])
+    assert n == f["n_reads"] and o.c.n_elem == c["raw"] and o.c.n_undefined == 0
+    o.finalise(c["remove_biased"], c["min_coverage"])
+    assert (o.c.n_elem, o.c.n_idx, o.c.coverage) == (c["n_elem"], c["n_idx"], c["coverage"])
+    assert o.c.n_alloc == o.c.n_elem and o.c.status == 0
+    e = o.elems()
+    assert (e["read_offset"] == -1).all()
+    # order: strictly decreasing in (base, ctx0, ctx1, length)
+    d = orc.decode_meta(e["meta"])
+    keys = list(zip(d["base"].tolist(), e["ctx0"].tolist(), e["ctx1"].tolist(), d["length"].tolist()))
+    assert all(keys[i] > keys[i + 1] for i in range(len(keys) - 1))
+    ii, ff = o.idx()
+    assert (ii < ff).all() and (ff[:-1] <= ii[1:]).all()
+
+
+def test_file_first_rows_and_pairing(known_answers, golden_dir):
+    f = known_answers["file"]
+    path = os.path.join(golden_dir, f["path"])
+    o = orc.Oracle(10)
+    o.scan_file(path, 3)
+    o.finalise(1, 5)
+    e = o.elems()
+    d = orc.decode_meta(e["meta"])
+    for i, r in enumerate(f["first_kept_rows_k10_m3_biased1"]):
+        assert (int(d["base"][i]), int(e["ctx0"][i]), int(e["ctx1"][i]), int(d["length"][i]), int(d["count"][i]),
+                int(d["canon_flag"][i])) == (r["base"], int(r["ctx0"], 16), int(r["ctx1"], 16), r["length"],
+                                             r["count"], r["canon_flag"])
+    # "paired" = the same file appended twice (reference has no mate logic: src/genome_set.c:72-73)
+    p = orc.Oracle(10)
+    p.scan_file(path, 3)
+    p.scan_file(path, 3)
+    assert p.c.n_elem == f["paired_same_file_twice_k10_m3"]["raw"]
+    p.finalise(1, 5)
+    pe = p.elems()
+    pd = orc.decode_meta(pe["meta"])
+    assert p.c.n_elem == f["paired_same_file_twice_k10_m3"]["n_elem"]
+    assert (pe["ctx0"] == e["ctx0"]).all() and (pe["ctx1"] == e["ctx1"]).all()
+    assert (pd["count"] == 2 * d["count"]).all()
+
+
+def test_state_machine_equals_closed_form():
+    rng = random.Random(20261003)
+    alphabets = ["ACGT", "ACGT", "AC", "ACGTN", "ACGTacgtUN-", "AT"]
+    for it in range(3000):
+        ab = alphabets[it % len(alphabets)]
+        L = rng.randint(0, 90)
+        # geometric-ish runs so that long tracts appear
+        s = []
+        while len(s) < L:
+            s.extend(rng.choice(ab) * rng.choice([1, 1, 1, 2, 3, 4, 5, 9]))
+        seq = "".join(s[:L])
+        k = rng.choice([2, 3, 4, 7, 10, 16, 25, 31, 32])
+        m = rng.choice([1, 2, 3, 4, 6])
+        o = orc.Oracle(k)
+        o.scan_seq(seq, m)
+        assert records_of(o, k) == scan_closed_form(seq, k, m), (seq, k, m)
+
+
+def test_stream_equals_per_read():
+    rng = random.Random(7)
+    reads = ["".join(rng.choice("ACGT") * rng.choice([1, 1, 2, 4]) for _ in range(rng.randint(0, 60))) for _ in range(200)]
+    reads[5] = ""            # empty read
+    a = orc.Oracle(5)
+    for r in reads:
+        a.scan_seq(r, 3)
+    b = orc.Oracle(5)
+    b.scan_stream(("\n".join(reads) + "\n").encode(), 3)
+    assert records_of(a, 5) == records_of(b, 5) and b.c.n_reads == len(reads)
+
+
+def test_finalise_empty_and_filtered_out():
+    o = orc.Oracle(3)
+    o.finalise(1, 5)
+    assert o.c.status == 1 and o.c.n_elem == 0
+    o = orc.Oracle(3)
+    o.scan_seq("CCGAAAAGAT", 3)          # one strand only -> removed by the strand filter
+    o.finalise(1, 0)
+    assert o.c.status == 2 and o.c.n_elem == 0 and o.c.ref_start == 0
+    o = orc.Oracle(3)
+    o.scan_seq("CCGAAAAGAT", 3)
+    o.scan_seq("ATCTTTTCGG", 3)          # both strands, depth 2 < 5
+    o.finalise(1, 5)
+    assert o.c.status == 3 and o.c.n_elem == 0
+    o = orc.Oracle(3)
+    o.scan_seq("CCGAAAAGAT", 3)
+    o.scan_seq("ATCTTTTCGG", 3)
+    o.finalise(1, 2)
+    assert o.c.status == 0 and o.c.n_elem == 1 and o.c.n_idx == 1 and o.c.coverage == 2
+    d = orc.decode_meta(o.elems()["meta"])
+    assert d["count"][0] == 2 and d["canon_flag"][0] == 3
