@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-job reads/s of the homopolymer-tract hot path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one sample's reads: scan kernel (tract detection + flank packing) followed
+by the device finalise (sort / reduce / filter / index / coverage), with the read stream already resident in HBM.
+Workload at N=1: BASELINE.json configs[1] -- 1 sample, 10 M synthetic 150 bp single-end reads from a 5 Mb genome,
+k=10, min_tract=3, strand-bias filter on, min_coverage=5.  With N>1 GPUs every rank holds its own sample of that size
+(weak scaling, samples are independent: reference src/genome_set.c:66-94) and the step ends with the exchange the
+path has: an all-gather (RCCL) of the per-sample histograms.
+
+Prints ONE JSON line on rank 0.  The CPU oracle is used only for the cpu_baseline leg (never in the timed GPU path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per sample (per GPU)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--genome", type=int, default=5_000_000)
+    ap.add_argument("--kmer", type=int, default=10)
+    ap.add_argument("--min-tract", type=int, default=3)
+    ap.add_argument("--min-coverage", type=int, default=5)
+    ap.add_argument("--cpu-reads", type=int, default=2_000_000, help="reads of the same sample timed on the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import tatajuba_amd as tj
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available() or tj.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    k, m, L = args.kmer, args.min_tract, args.read_len
+    # one sample per rank: same genome, per-sample tract-length variants and read seeds (SURVEY 8d config 4 recipe)
+    host = tj.synth_stream(args.reads, L, args.genome, seed_reads=0x7A7A1000 + rank,
+                           variant_seed=(rank if world > 1 else 0), n_threads=max(1, 16 // max(1, min(world, 8))))
+    n_bytes = host.size
+    dev = torch.from_numpy(host).cuda()                 # resident in HBM before the timed region
+    stream = torch.cuda.current_stream()
+    c = tj.Counter(k, device=local)
+    c.set_stream(stream.cuda_stream)
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        c.reset()
+        c.scan_device(dev.data_ptr(), n_bytes, m)
+        st = c.finalise(1, args.min_coverage)
+        if st != 0:
+            raise SystemExit(f"finalise status {st}")
+        if world > 1:                                     # exchange step: all-gatherv of the per-sample histograms
+            from tatajuba_amd.dist import all_gather_histograms
+            gathered = all_gather_histograms(c, dist)
+        return c.last_scan_ms(), c.last_finalise_ms()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    scan_ms, fin_ms = [], []
+    for _ in range(args.steps):
+        a, b = step()
+        scan_ms.append(a); fin_ms.append(b)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    raw = c.raw_count()
+    kept = c.n_kept
+    scan_avg = float(np.mean(scan_ms))
+    fin_avg = float(np.mean(fin_ms))
+    total_reads = args.reads * world * args.steps
+    value = total_reads / dt
+
+    # roofline of the scan kernel: algorithmic bytes = the stream itself, (L + 1) bytes per read in this layout
+    # (SURVEY 8d quotes L + 8 for an offsets-table layout; the sentinel layout carries boundaries in-band -- DESIGN.md)
+    scan_bytes = float(n_bytes)
+    scan_gbs = scan_bytes / (scan_avg * 1e-3) / 1e9
+    # sort+reduce stage: one-pass bound read 24 B per raw record, write 24 B per kept record
+    fin_bytes = 24.0 * raw + 24.0 * kept
+    fin_gbs = fin_bytes / (fin_avg * 1e-3) / 1e9
+    dominant = "scan" if scan_avg >= fin_avg else "finalise"
+    roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None}
+    if dominant == "scan":
+        roof.update({"kernel": "scan_kernel<3>", "achieved": scan_gbs, "frac": scan_gbs / HBM_PEAK_GBS,
+                     "ms": scan_avg, "algorithmic_bytes": scan_bytes})
+    else:
+        roof.update({"kernel": "finalise (radix_scatter_kernel dominates)", "achieved": fin_gbs, "frac": fin_gbs / HBM_PEAK_GBS,
+                     "ms": fin_avg, "algorithmic_bytes": fin_bytes})
+
+    out = {
+        "metric": "reads/s (whole node), 150 bp synthetic FASTQ, homopolymer scan + context histogram",
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/u64", "data": "synthetic",
+        "config": {"workload": f"{world} sample(s) x {args.reads} synthetic {L} bp single-end reads, genome {args.genome} bp, "
+                               f"k={k} min_tract={m} remove_biased=1 min_coverage={args.min_coverage} (BASELINE.json configs[1] per GPU)",
+                   "reads_per_gpu": args.reads, "raw_records_per_gpu": int(raw), "kept_records": int(kept),
+                   "parallelism": f"sample-per-gpu x{world}"},
+        "roofline": roof,
+        "stages": {"scan": {"ms": scan_avg, "algorithmic_GBps": scan_gbs, "frac_of_hbm_peak": scan_gbs / HBM_PEAK_GBS,
+                            "reads_per_s": args.reads / (scan_avg * 1e-3)},
+                   "finalise": {"ms": fin_avg, "algorithmic_GBps": fin_gbs, "frac_of_hbm_peak": fin_gbs / HBM_PEAK_GBS}},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import orc                             # checker / baseline only
+        n_cpu = min(args.cpu_reads, args.reads)
+        sample = host[: n_cpu * (L + 1)]
+        o = orc.Oracle(k)
+        t1 = time.perf_counter()
+        o.scan_stream(sample, m)
+        t2 = time.perf_counter()
+        o.finalise(1, args.min_coverage)
+        t3 = time.perf_counter()
+        out["cpu_baseline"] = {"value": n_cpu / (t3 - t1), "unit": "reads/s", "cores": 1, "kind": "port",
+                               "sample": f"first {n_cpu} reads of the same sample; scan {t2 - t1:.2f} s + sort/dedupe/filter {t3 - t2:.2f} s "
+                                         f"on 1 core (the reference runs one thread per sample: src/genome_set.c:66-68); "
+                                         f"parse/inflate excluded on both sides",
+                               "host_cores_available": os.cpu_count()}
+    if rank == 0:
+        print(json.dumps(out))
+    c.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+/* tatajuba_amd.h -- C-ABI extension of the drop-in boundary (tatajuba_hopo.h) for callers that hold their reads in
+ * device memory, drive several GPUs, or want to inspect the device-side state.  Everything is extern "C", plain
+ * pointers and sizes; `void *hip_stream` is a hipStream_t (NULL = the counter's own stream).
+ *
+ * A "stream of reads" (the batch format of the device path) is a byte buffer in which every read is followed by one
+ * '\n' (0x0A) -- the one byte tatajuba's parser can never deliver inside a sequence (reference: src/kseq.h:105,189-192).
+ * It carries read boundaries in-band, so the scan kernel needs no offset table.
+ *
+ * Reference interfaces replaced:
+ *   tjamd_scan_*      : the loop `while (kseq_read) update_hopo_counter_from_seq(...)`   src/hopo_counter.c:153,219-258,285-307
+ *   tjamd_finalise    : finalise_hopo_counter() steps 1-4 + coverage                     src/hopo_counter.c:339-415,419-438
+ *   tjamd_download_*  : the caller's direct reads of hc->elem / idx_* / coverage          src/context_histogram.c:231-256
+ */
+#ifndef TATAJUBA_AMD_H
+#define TATAJUBA_AMD_H
+
+#include "tatajuba_hopo.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bit positions inside the 64-bit word of hopo_element / of a device record (see tatajuba_hopo.h) */
+#define TJ_META_BASE_SHIFT   0
+#define TJ_META_LEN_SHIFT    2
+#define TJ_META_COUNT_SHIFT  12
+#define TJ_META_MISM_SHIFT   32
+#define TJ_META_FLAG_SHIFT   49
+#define TJ_META_RAW_CONST    ((1ULL << TJ_META_COUNT_SHIFT) | (0xffeULL << TJ_META_MISM_SHIFT)) /* count=1, mismatches=0xffe */
+
+typedef struct tjamd_counter tjamd_counter;      /* device-side per-sample accumulator (opaque) */
+
+/* 24-byte device record: context[0], context[1], bitfield word.  32-byte "located" record adds the global byte
+ * position of the tract's first base in the scanned stream (test / CPU-entry aid; gives emission order and read_offset). */
+typedef struct { uint64_t ctx0, ctx1, meta; } tjamd_record;
+typedef struct { uint64_t ctx0, ctx1, meta, pos; } tjamd_located_record;
+
+/* error codes (0 = ok) */
+enum { TJAMD_OK = 0, TJAMD_ERR_NO_DEVICE = 1, TJAMD_ERR_HIP = 2, TJAMD_ERR_ARG = 3, TJAMD_ERR_CAPACITY = 4, TJAMD_ERR_STATE = 5 };
+
+int  tjamd_device_count (void);                   /* number of visible HIP devices (0 => every entry below fails loudly) */
+const char *tjamd_last_error (void);              /* thread-local message of the last failure */
+const char *tjamd_version (void);
+
+tjamd_counter *tjamd_counter_create (int device, int kmer_size);   /* NULL on failure (see tjamd_last_error) */
+void tjamd_counter_destroy (tjamd_counter *c);
+int  tjamd_counter_reset (tjamd_counter *c);      /* forget raw and finalised records, keep buffers */
+int  tjamd_counter_set_stream (tjamd_counter *c, void *hip_stream); /* run on the caller's stream (e.g. torch's) */
+int  tjamd_counter_device (const tjamd_counter *c);
+
+/* Scan a stream of reads already resident in this counter's device memory.  d_stream must be 16-byte aligned.
+ * Asynchronous; appends to the counter's raw records. */
+int  tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t n_bytes, int min_tract_size);
+/* Same from host memory (copied to HBM first). */
+int  tjamd_scan_host (tjamd_counter *c, const void *h_stream, size_t n_bytes, int min_tract_size);
+/* Located variant: records go to a separate list with positions, sorted by position (emission order) on download. */
+long tjamd_scan_host_located (tjamd_counter *c, const void *h_stream, size_t n_bytes, int min_tract_size,
+                              tjamd_located_record *out, long capacity);
+
+/* Host-only: parse a FASTA/FASTQ file (plain or gzip; same record semantics as the reference's reader, src/kseq.h:172-212
+ * as looped at src/hopo_counter.c:153) into a stream of reads.  Returns the stream's size in bytes and writes it to out
+ * when capacity suffices (call with out = NULL to size); *n_reads = records parsed; -1 if the file cannot be opened. */
+long tjamd_read_file_stream (const char *path, unsigned char *out, long capacity, long *n_reads);
+
+/* pinned host memory, so that tjamd_scan_host overlaps the copy with the caller's parsing; tjamd_sync waits for
+ * everything queued on the counter's stream */
+void *tjamd_host_alloc (size_t bytes);
+void tjamd_host_free (void *p);
+int  tjamd_sync (tjamd_counter *c);
+
+long tjamd_raw_count (tjamd_counter *c);          /* synchronises; number of raw records so far; <0 on error */
+long tjamd_download_raw (tjamd_counter *c, tjamd_record *out, long capacity); /* unordered multiset */
+long tjamd_undefined_runs (tjamd_counter *c);     /* qualifying non-ACGTU runs with no earlier tract in the read (dropped) */
+/* append host-produced raw records (hopo_element array) to the device raw list */
+int  tjamd_upload_raw (tjamd_counter *c, const hopo_element *elems, long n);
+
+/* steps 1-4 + coverage on the device.  status: 0 ok, 1 no raw records, 2 nothing after filter, 3 nothing reaches
+ * min_coverage (reference: src/hopo_counter.c:345-349,376-381,406-411). */
+int  tjamd_finalise (tjamd_counter *c, int remove_biased, int min_coverage, int *status);
+long tjamd_kept_count (tjamd_counter *c);
+int  tjamd_n_idx (tjamd_counter *c);
+int  tjamd_coverage (tjamd_counter *c);
+long tjamd_download_kept (tjamd_counter *c, hopo_element *out, long capacity);      /* widened to 40-byte elements */
+long tjamd_download_idx (tjamd_counter *c, int *idx_initial, int *idx_final, long capacity);
+const void *tjamd_kept_device_ptr (tjamd_counter *c);   /* tjamd_record[kept_count] in HBM (for collectives) */
+
+/* cross-sample merge on one device (reference precursor of src/genome_set.c:250-289, keyed by context instead of
+ * BWA location): concatenation of n_samples kept arrays (d_records, counts[]) -> sorted union with per-sample counts.
+ * out_keys: tjamd_record[n_union] (count field = total), out_counts: int32[n_union * n_samples].  Returns n_union. */
+long tjamd_merge_samples (tjamd_counter *c, const void *d_records, const long *counts, int n_samples,
+                          void *d_out_keys, void *d_out_counts, long capacity);
+
+/* timing of the last operations on this counter, from HIP events on its stream (milliseconds) */
+double tjamd_last_scan_ms (tjamd_counter *c);       /* scan kernel(s) of the last tjamd_scan_* call */
+double tjamd_last_finalise_ms (tjamd_counter *c);   /* whole device finalise of the last tjamd_finalise call */
+long   tjamd_last_scan_launches (tjamd_counter *c);
+
+/* synthetic inputs: genome of `genome_len` i.i.d. bases from splitmix64(seed_genome); n_reads reads of
+ * length read_len (or uniform in [read_len, read_len_max] when read_len_max > read_len), uniform start, strand by coin,
+ * no N, written as a stream of reads into out (capacity bytes).  variant_seed != 0 lengthens/shortens 1% of the
+ * genome's tracts >= 4 by one base first.  Returns bytes written, or -(bytes needed) if capacity is too small. */
+long tjamd_synth_stream (uint64_t seed_genome, uint64_t seed_reads, uint64_t variant_seed, long genome_len,
+                         long n_reads, int read_len, int read_len_max, unsigned char *out, long capacity, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,334 @@
+/* hopo_host.c -- C host side of the drop-in boundary (include/tatajuba_hopo.h).
+ *
+ * Same function names, argument meaning and error behaviour as tatajuba's src/hopo_counter.c for the per-read scan and
+ * the per-sample finalise, but the work is done by the HIP kernels behind the tjamd_* C-ABI (hopo_device.hip).  There
+ * is NO CPU implementation of the scan or of the sort/reduce in this library: without an MI355X every entry that
+ * needs results prints an error and exits, like the reference's biomcmc_error().
+ */
+#include "../../include/tatajuba_amd.h"
+#include "fastq_reader.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+
+/* ---- tables (reference: src/hopo_counter.c:10-11,205-216; constant here, so no lazy-initialisation race) -------- */
+
+#define TJ_OTHER {4, 4}
+uint8_t dna_in_2_bits[256][2] = {
+  [0 ... 255] = TJ_OTHER,
+  ['A'] = {0, 3}, ['a'] = {0, 3}, ['C'] = {1, 2}, ['c'] = {1, 2}, ['G'] = {2, 1}, ['g'] = {2, 1},
+  ['T'] = {3, 0}, ['t'] = {3, 0}, ['U'] = {3, 0}, ['u'] = {3, 0}
+};
+char bit_2_dna[] = {'A', 'C', 'G', 'T'};
+
+/* ---- private state appended to the public struct ------------------------------------------------------------------ */
+
+#define TJ_PRIV_MAGIC 0x746a616d64686f70ULL
+#define TJ_BATCH_BYTES (64u << 20)
+
+typedef struct
+{
+  uint64_t magic;
+  tjamd_counter *dev;
+  int n_host;            /* records in hc->elem[] that were produced by update_hopo_counter_from_seq */
+  long n_device;         /* raw records held on the device */
+} tj_private;
+
+static inline tj_private *tj_priv (hopo_counter hc) { return (tj_private *) (hc + 1); }
+
+static void
+tj_fatal (const char *fmt, ...)
+{ /* biomcmc_error(): message, then exit(EXIT_FAILURE) */
+  va_list ap;
+  fprintf (stderr, "tatajuba_amd error: ");
+  va_start (ap, fmt); vfprintf (stderr, fmt, ap); va_end (ap);
+  fprintf (stderr, "\n");
+  exit (EXIT_FAILURE);
+}
+
+static void
+tj_warning (const char *fmt, ...)
+{
+  va_list ap;
+  fprintf (stderr, "tatajuba_amd warning: ");
+  va_start (ap, fmt); vfprintf (stderr, fmt, ap); va_end (ap);
+  fprintf (stderr, "\n");
+}
+
+static int tj_next_device = 0;
+
+/* sample i -> device i mod N (the reference runs one OpenMP thread per sample: src/genome_set.c:66-94);
+ * TATAJUBA_AMD_DEVICE pins every counter of the process to one device (one process per GPU under torchrun). */
+static tjamd_counter *
+tj_device_counter (hopo_counter hc)
+{
+  tj_private *pv = tj_priv (hc);
+  if (!pv->dev) {
+    int n = tjamd_device_count (), dev;
+    const char *pin = getenv ("TATAJUBA_AMD_DEVICE");
+    if (n <= 0) tj_fatal ("no HIP device is visible; the homopolymer scan runs on an MI355X only (there is no CPU fallback)");
+    dev = pin ? atoi (pin) : (__atomic_fetch_add (&tj_next_device, 1, __ATOMIC_RELAXED) % n);
+    pv->dev = tjamd_counter_create (dev, hc->kmer_size);
+    if (!pv->dev) tj_fatal ("%s", tjamd_last_error ());
+  }
+  return pv->dev;
+}
+
+/* ---- constructor / destructor (reference: src/hopo_counter.c:159-186) ---------------------------------------------- */
+
+hopo_counter
+new_hopo_counter (int kmer_size)
+{
+  hopo_counter hc = (hopo_counter) calloc (1, sizeof (struct hopo_counter_struct) + sizeof (tj_private));
+  if (!hc) tj_fatal ("out of memory");
+  hc->n_alloc = 32;
+  hc->kmer_size = kmer_size;
+  hc->n_idx = hc->n_elem = 0;
+  hc->coverage = 0;
+  hc->elem = (hopo_element *) malloc ((size_t) hc->n_alloc * sizeof (hopo_element));
+  hc->ref_counter = 1;
+  hc->name = NULL; hc->idx_initial = hc->idx_final = NULL;
+  tj_priv (hc)->magic = TJ_PRIV_MAGIC;
+  return hc;
+}
+
+void
+del_hopo_counter (hopo_counter hc)
+{
+  if (!hc) return;
+  if (--hc->ref_counter) return;
+  if (tj_priv (hc)->magic == TJ_PRIV_MAGIC && tj_priv (hc)->dev) tjamd_counter_destroy (tj_priv (hc)->dev);
+  free (hc->elem); free (hc->name); free (hc->idx_initial); free (hc->idx_final);
+  free (hc);
+}
+
+/* ---- file -> device (reference: src/hopo_counter.c:135-157) -------------------------------------------------------- */
+
+hopo_counter
+new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tatajuba_options_t opt)
+{
+  hopo_counter h = hc;
+  tjamd_counter *dev;
+  tjr_reader *rd;
+  unsigned char *buf[2] = {NULL, NULL};
+  size_t fill = 0;
+  int cur = 0, in_flight = 0;
+  long len, n;
+  const char *seq;
+
+  if (!h) {
+    h = new_hopo_counter (opt.kmer_size);
+    h->name = (char *) malloc (strlen (filename) + 1);
+    strcpy (h->name, filename);
+    h->opt = opt;
+  }
+  if (h->idx_initial) tj_fatal ("This counter has been compared to another; cannot add more reads to it"); /* reference :152 */
+  rd = tjr_open (filename);
+  if (!rd) tj_fatal ("cannot open '%s' (the reference leaves gzopen unchecked, src/hopo_counter.c:142; this build stops)", filename);
+  dev = tj_device_counter (h);
+  buf[0] = (unsigned char *) tjamd_host_alloc (TJ_BATCH_BYTES);
+  buf[1] = (unsigned char *) tjamd_host_alloc (TJ_BATCH_BYTES);
+  if (!buf[0] || !buf[1]) tj_fatal ("%s", tjamd_last_error ());
+
+  while ((len = tjr_next (rd, &seq)) >= 0) {           /* -2 (bad quality string) ends the file silently, as in the reference */
+    if ((size_t) len + 1 > TJ_BATCH_BYTES) {            /* one read larger than a batch: send it on its own */
+      unsigned char *big = (unsigned char *) malloc ((size_t) len + 1);
+      memcpy (big, seq, (size_t) len); big[len] = '\n';
+      if (fill) { if (tjamd_scan_host (dev, buf[cur], fill, opt.min_tract_size)) tj_fatal ("%s", tjamd_last_error ()); fill = 0; }
+      if (tjamd_scan_host (dev, big, (size_t) len + 1, opt.min_tract_size) || tjamd_sync (dev)) tj_fatal ("%s", tjamd_last_error ());
+      free (big);
+      in_flight = 0;
+      continue;
+    }
+    if (fill + (size_t) len + 1 > TJ_BATCH_BYTES) {     /* batch full: queue copy + scan, parse on into the other buffer */
+      if (in_flight && tjamd_sync (dev)) tj_fatal ("%s", tjamd_last_error ()); /* the other buffer's copy must be done */
+      if (tjamd_scan_host (dev, buf[cur], fill, opt.min_tract_size)) tj_fatal ("%s", tjamd_last_error ());
+      in_flight = 1; cur ^= 1; fill = 0;
+    }
+    memcpy (buf[cur] + fill, seq, (size_t) len);
+    buf[cur][fill + (size_t) len] = '\n';
+    fill += (size_t) len + 1;
+  }
+  if (fill && tjamd_scan_host (dev, buf[cur], fill, opt.min_tract_size)) tj_fatal ("%s", tjamd_last_error ());
+  tjr_close (rd);
+  n = tjamd_raw_count (dev);                            /* synchronises the stream */
+  if (n < 0) tj_fatal ("%s", tjamd_last_error ());
+  tjamd_host_free (buf[0]); tjamd_host_free (buf[1]);
+  tj_priv (h)->n_device = n;
+  h->n_elem = tj_priv (h)->n_host + (int) n;
+  return h;
+}
+
+long
+tjamd_read_file_stream (const char *path, unsigned char *out, long capacity, long *n_reads)
+{
+  tjr_reader *rd = tjr_open (path);
+  long total = 0, n = 0, len;
+  const char *seq;
+  if (!rd) return -1;
+  while ((len = tjr_next (rd, &seq)) >= 0) {
+    if (out && total + len + 1 <= capacity) { memcpy (out + total, seq, (size_t) len); out[total + len] = '\n'; }
+    total += len + 1; n++;
+  }
+  tjr_close (rd);
+  if (n_reads) *n_reads = n;
+  return total;
+}
+
+/* ---- one sequence, synchronously (reference: src/hopo_counter.c:219-258) ------------------------------------------ */
+
+void
+update_hopo_counter_from_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size)
+{
+  tj_private *pv = tj_priv (hc);
+  tjamd_counter *dev;
+  tjamd_located_record *rec;
+  unsigned char *stream;
+  long i, n, cap;
+
+  if (seq_length <= hc->kmer_size) return;              /* reference loop bound :226 */
+  dev = tj_device_counter (hc);
+  cap = seq_length / 2 + 2;
+  stream = (unsigned char *) malloc ((size_t) seq_length + 1);
+  rec = (tjamd_located_record *) malloc ((size_t) cap * sizeof (tjamd_located_record));
+  memcpy (stream, seq, (size_t) seq_length);
+  stream[seq_length] = '\n';
+  n = tjamd_scan_host_located (dev, stream, (size_t) seq_length + 1, min_tract_size, rec, cap);
+  if (n < 0) tj_fatal ("%s", tjamd_last_error ());
+  for (i = 0; i < n; i++) {                             /* reference add_kmer_to_hopo_counter :285-307 */
+    hopo_element *e;
+    if (pv->n_host == hc->n_alloc) {
+      hc->n_alloc *= 2;
+      hc->elem = (hopo_element *) realloc (hc->elem, (size_t) hc->n_alloc * sizeof (hopo_element));
+    }
+    e = hc->elem + pv->n_host++;
+    e->context[0] = rec[i].ctx0; e->context[1] = rec[i].ctx1;
+    memcpy ((char *) e + 16, &rec[i].meta, 8);
+    e->read_offset = (int32_t) ((long) rec[i].pos - hc->kmer_size);
+    e->loc_ref_id = e->loc_pos = e->loc_last = -1;
+  }
+  hc->n_elem = pv->n_host + (int) pv->n_device;
+  free (rec); free (stream);
+}
+
+/* ---- finalise (reference: src/hopo_counter.c:339-417) ------------------------------------------------------------- */
+
+void
+finalise_hopo_counter (hopo_counter hc)
+{
+  tj_private *pv = tj_priv (hc);
+  tjamd_counter *dev;
+  int status = 0;
+  long n1;
+
+  if (!hc->n_elem) {                                    /* reference :345-349 */
+    hc->ref_start = hc->n_elem = 0;
+    tj_warning ("No HTs were found in sample %s%s, not even before QC. This sample will be excluded.", hc->name, (hc->opt.paired_end ? " together with its pair." : "."));
+    return;
+  }
+  dev = tj_device_counter (hc);
+  if (pv->n_host && tjamd_upload_raw (dev, hc->elem, pv->n_host)) tj_fatal ("%s", tjamd_last_error ());
+  if (tjamd_finalise (dev, hc->opt.remove_biased, hc->opt.min_coverage, &status)) tj_fatal ("%s", tjamd_last_error ());
+  pv->n_host = 0; pv->n_device = 0;
+
+  if (status == 1) { hc->ref_start = hc->n_elem = 0; return; }
+  if (status == 2) {                                    /* reference :376-381 */
+    hc->ref_start = hc->n_elem = 0;
+    if (hc->opt.remove_biased) tj_warning ("No HTs found in sample %s after excluding those present only in one strand. This sample will be excluded.", hc->name);
+    else tj_warning ("No HTs found in sample %s %s after excluding those seen only once. This sample will be excluded.", hc->name, (hc->opt.paired_end ? "(and pair)" : ""));
+    return;
+  }
+  n1 = tjamd_kept_count (dev);                          /* reference :382-386 */
+  free (hc->elem);
+  hc->elem = (hopo_element *) malloc ((size_t) n1 * sizeof (hopo_element));
+  if (tjamd_download_kept (dev, hc->elem, n1) != n1) tj_fatal ("%s", tjamd_last_error ());
+  hc->n_alloc = hc->n_elem = (int) n1;
+
+  if (status == 3) {                                    /* reference :406-411 (index arrays stay allocated, n_idx = 0) */
+    hc->idx_initial = (int *) malloc ((size_t) n1 * sizeof (int));
+    hc->idx_final = (int *) malloc ((size_t) n1 * sizeof (int));
+    hc->n_idx = 0;
+    hc->ref_start = hc->n_elem = 0;
+    tj_warning ("From the HTs found in sample %s%s, not a single one has coverage higher than %d. This sample will be excluded. Try decreasing the 'Min depth of tract lengths'.",
+                hc->name, (hc->opt.paired_end ? " (together with its pair)" : ""), hc->opt.min_coverage);
+    return;
+  }
+  hc->n_idx = tjamd_n_idx (dev);                        /* reference :412-413 */
+  hc->idx_initial = (int *) malloc ((size_t) hc->n_idx * sizeof (int));
+  hc->idx_final = (int *) malloc ((size_t) hc->n_idx * sizeof (int));
+  if (tjamd_download_idx (dev, hc->idx_initial, hc->idx_final, hc->n_idx) != hc->n_idx) tj_fatal ("%s", tjamd_last_error ());
+  hc->coverage = tjamd_coverage (dev);                  /* reference :415 */
+  if (find_reference_location_and_sort_hopo_counter) find_reference_location_and_sort_hopo_counter (hc); /* :416, if linked */
+}
+
+/* ---- host helpers kept for callers (not on the accelerated path) --------------------------------------------------- */
+
+int
+compare_hopo_element_decreasing (const void *a, const void *b)
+{ /* reference: src/hopo_counter.c:28-38 */
+  const hopo_element *x = (const hopo_element *) a, *y = (const hopo_element *) b;
+  int d = y->base - x->base;
+  if (d) return d;
+  if (y->context[0] != x->context[0]) return y->context[0] > x->context[0] ? 1 : -1;
+  if (y->context[1] != x->context[1]) return y->context[1] > x->context[1] ? 1 : -1;
+  return y->length - x->length;
+}
+
+int
+compare_hopo_context (hopo_element a, hopo_element b)
+{ /* reference: src/hopo_counter.c:48-58 */
+  int d = b.base - a.base;
+  if (d) return d;
+  if (b.context[0] != a.context[0]) return b.context[0] > a.context[0] ? 1 : -1;
+  if (b.context[1] != a.context[1]) return b.context[1] > a.context[1] ? 1 : -1;
+  return 0;
+}
+
+char *
+generate_tract_as_string (uint64_t *context, int8_t base, int kmer_size, int tract_length, bool neg_strand)
+{ /* reference: src/hopo_counter.c:447-469: left flank, tract, right flank; reverse-complemented when neg_strand */
+  int n = 2 * kmer_size + tract_length, i;
+  char *s = (char *) malloc ((size_t) n + 1);
+  for (i = 0; i < kmer_size; i++) s[i] = bit_2_dna[(context[0] >> (2 * i)) & 3];
+  for (i = 0; i < tract_length; i++) s[kmer_size + i] = bit_2_dna[base & 3];
+  for (i = 0; i < kmer_size; i++) s[kmer_size + tract_length + i] = bit_2_dna[(context[1] >> (2 * i)) & 3];
+  s[n] = '\0';
+  if (neg_strand)
+    for (i = 0; i < (n + 1) / 2; i++) {
+      char a = s[i], b = s[n - 1 - i];
+      s[i] = bit_2_dna[3 - dna_in_2_bits[(unsigned char) b][0]];
+      s[n - 1 - i] = bit_2_dna[3 - dna_in_2_bits[(unsigned char) a][0]];
+    }
+  return s;
+}
+
+char *
+generate_name_from_flanking_contexts (uint64_t *context, int8_t base, int kmer_size, bool neg_strand)
+{ /* reference: src/hopo_counter.c:471-493: "left.B.right" */
+  char *t = generate_tract_as_string (context, base, kmer_size, 1, neg_strand);
+  char *s = (char *) malloc ((size_t) (2 * kmer_size + 4));
+  memcpy (s, t, (size_t) kmer_size);
+  s[kmer_size] = '.'; s[kmer_size + 1] = t[kmer_size]; s[kmer_size + 2] = '.';
+  memcpy (s + kmer_size + 3, t + kmer_size + 1, (size_t) kmer_size);
+  s[2 * kmer_size + 3] = '\0';
+  free (t);
+  return s;
+}
+
+void
+print_tatajuba_options (tatajuba_options_t opt)
+{ /* reference: src/hopo_counter.c:115-133 (the GFF3 prefix lives in biomcmc's struct, which is opaque here) */
+  fprintf (stderr, "%s\n", tjamd_version ());
+  fprintf (stderr, "Reference genome fasta file: %s\n", opt.reference_fasta_filename ? opt.reference_fasta_filename : "(none)");
+  fprintf (stderr, "Output directory:            %s\n", opt.outdir ? opt.outdir : "(none)");
+  fprintf (stderr, "Number of samples:           %5d (%s)\n", opt.n_samples, (opt.paired_end ? "paired-end" : "single-end"));
+  fprintf (stderr, "Max distance per flanking k-mer:  %6d\n", opt.max_distance_per_flank);
+  fprintf (stderr, "Levenshtein distance for merging: %6d\n", opt.levenshtein_distance);
+  fprintf (stderr, "Flanking k-mer size (context):    %6d\n", opt.kmer_size);
+  fprintf (stderr, "Min tract length to consider:     %6d\n", opt.min_tract_size);
+  fprintf (stderr, "Min depth of tract lengths:       %6d\n", opt.min_coverage);
+  fprintf (stderr, "Remove biased tracts:             %s\n", (opt.remove_biased ? "yes" : "no"));
+  if (opt.n_threads) fprintf (stderr, "Number of threads (requested or optimised): %3d\n", opt.n_threads);
+  fprintf (stderr, "HIP devices visible: %d\n", tjamd_device_count ());
+}

@@ -1,0 +1,63 @@
+"""Multi-GPU plumbing: one process per GPU, samples sharded one per rank (the reference's unit of parallelism is the
+sample: src/genome_set.c:66-94).  The only exchange on the path is the all-gatherv of the per-sample histograms (the kept
+24-byte records) ahead of the cross-sample merge (reference: src/genome_set.c:195-229,250-289).  torch.distributed is
+plumbing here: backend "nccl" is RCCL over xGMI on the GPU node, "gloo" in the CPU tests."""
+import numpy as np
+import torch
+
+RECORD_BYTES = 24
+
+
+class _DevMem:
+    """zero-copy view of device memory owned by the C library"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_bytes_tensor(ptr, nbytes, device):
+    return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
+
+
+def all_gatherv_bytes(local, dist, group=None):
+    """all-gatherv of a 1-D uint8 tensor: sizes first, then one padded all_gather (xGMI is point-to-point, the payloads
+    are MB-scale: one collective on max-padded blocks beats a ring of sends).  Returns (list of tensors, sizes)."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    pad = torch.zeros(mx, dtype=torch.uint8, device=local.device)
+    pad[: local.numel()] = local
+    out = [torch.empty(mx, dtype=torch.uint8, device=local.device) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return [o[:s] for o, s in zip(out, sizes)], sizes
+
+
+def all_gather_histograms(counter, dist, group=None):
+    """Gather every rank's kept records (device-resident, straight from the library's buffer).
+    Returns (uint8 tensor of all records concatenated in rank order, list of record counts)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = counter.n_kept
+    local = device_bytes_tensor(counter.kept_device_ptr, n * RECORD_BYTES, dev) if n else torch.empty(0, dtype=torch.uint8, device=dev)
+    parts, sizes = all_gatherv_bytes(local, dist, group)
+    return torch.cat(parts), [s // RECORD_BYTES for s in sizes]
+
+
+def merge_histograms_host(records_u8, counts):
+    """Context-keyed union of the samples' histograms on the host (numpy; small: 1e5-1e6 records per sample).
+    Key = (base, ctx0, ctx1, length) in the reference's descending order; returns (keys structured array, int32 matrix
+    [n_union, n_samples] of per-sample depths).  Precursor of the location-keyed merge of src/genome_set.c:250-289,
+    which needs the (out-of-scope) BWA locations."""
+    from .capi import RECORD_DTYPE, decode_meta
+    rec = np.frombuffer(records_u8.tobytes() if not isinstance(records_u8, (bytes, bytearray)) else records_u8, dtype=RECORD_DTYPE)
+    sample = np.repeat(np.arange(len(counts)), counts)
+    d = decode_meta(rec["meta"])
+    key = np.zeros(len(rec), dtype=[("base", "i8"), ("ctx0", "u8"), ("ctx1", "u8"), ("length", "i8")])
+    key["base"], key["ctx0"], key["ctx1"], key["length"] = d["base"], rec["ctx0"], rec["ctx1"], d["length"]
+    uniq, inv = np.unique(key, return_inverse=True)
+    uniq, inv = uniq[::-1], (len(uniq) - 1 - inv)          # descending
+    mat = np.zeros((len(uniq), len(counts)), dtype=np.int32)
+    np.add.at(mat, (inv, sample), d["count"].astype(np.int32))
+    return uniq, mat

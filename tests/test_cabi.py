@@ -1,0 +1,175 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol the two headers declare, struct
+layouts match the reference ABI, the host-only pieces (tables, name strings, reader, generator) behave, and the
+device entries fail loudly without a GPU.  No compute call is made here."""
+import ctypes as C
+import gzip
+import os
+import re
+
+import numpy as np
+import pytest
+
+import tatajuba_amd as tj
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b([a-z_][a-z0-9_]*)\s*\(", txt))
+    names |= set(re.findall(r"extern\s+\w+\s+(\w+)\s*\[", txt))
+    return {n for n in names if not n.startswith("__") and n not in ("defined", "sizeof")}
+
+
+def test_library_exports_every_declared_symbol():
+    L = tj.lib()
+    declared = (_declared("tatajuba_hopo.h") | _declared("tatajuba_amd.h"))
+    declared.discard("find_reference_location_and_sort_hopo_counter")     # weak import, provided by the host program
+    assert declared == set(tj.EXPORTS), declared ^ set(tj.EXPORTS)
+    for name in tj.EXPORTS:
+        assert hasattr(L, name) or C.c_char.in_dll(L, name) is not None, name
+
+
+def test_struct_layouts_match_reference_abi():
+    from tatajuba_amd.capi import Options, _HopoCounterStruct
+    assert C.sizeof(Options) == 64 and C.sizeof(_HopoCounterStruct) == 136      # SURVEY 8a (probed on the reference)
+    assert Options.gff.offset == 24 and Options.kmer_size.offset == 36 and Options.min_coverage.offset == 48
+    assert _HopoCounterStruct.opt.offset == 64 and _HopoCounterStruct.ref_counter.offset == 128
+    assert tj.ELEM_DTYPE.itemsize == 40 and tj.RECORD_DTYPE.itemsize == 24 and tj.LOCATED_DTYPE.itemsize == 32
+
+
+def test_tables_match_reference_encoding():
+    L = tj.lib()
+    tab = np.ctypeslib.as_array((C.c_uint8 * 512).in_dll(L, "dna_in_2_bits")).reshape(256, 2)
+    exp = np.full((256, 2), 4, np.uint8)
+    for ch, f in zip("ACGTU", [0, 1, 2, 3, 3]):
+        for c in (ch, ch.lower()):
+            exp[ord(c)] = (f, 3 - f)
+    assert (tab == exp).all()
+    assert bytes((C.c_char * 4).in_dll(L, "bit_2_dna")) == b"ACGT"
+
+
+def test_name_and_tract_strings():
+    L = tj.lib()
+    ctx = (C.c_uint64 * 2)(0x25, 0x32)
+    libc = C.CDLL(None)
+    p = L.generate_name_from_flanking_contexts(ctx, 0, 3, False)
+    assert C.string_at(p) == b"CCG.A.GAT"; libc.free(C.c_void_p(p))
+    p = L.generate_name_from_flanking_contexts(ctx, 0, 3, True)
+    assert C.string_at(p) == b"ATC.T.CGG"; libc.free(C.c_void_p(p))
+    p = L.generate_tract_as_string(ctx, 0, 3, 4, False)
+    assert C.string_at(p) == b"CCGAAAAGAT"; libc.free(C.c_void_p(p))
+    p = L.generate_tract_as_string(ctx, 0, 3, 4, True)
+    assert C.string_at(p) == b"ATCTTTTCGG"; libc.free(C.c_void_p(p))
+
+
+def test_new_and_del_counter_without_gpu():
+    h = tj.HopoCounter.new(10)
+    assert h.c.n_alloc == 32 and h.c.n_elem == 0 and h.c.kmer_size == 10 and h.c.ref_counter == 1
+    assert not h.c.idx_initial and h.c.name is None
+    h.c.opt = tj.Options.defaults(10, 3)
+    h.finalise()                      # empty counter: warning + excluded, no device needed (reference :345-349)
+    assert h.c.n_elem == 0 and h.c.ref_start == 0
+    h.delete()
+
+
+@pytest.mark.skipif(tj.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_device_entries_fail_loudly_without_gpu():
+    with pytest.raises(tj.TatajubaAmdError, match="no HIP device"):
+        tj.Counter(10)
+
+
+def _write(path, text, gz=False):
+    data = text.encode("latin-1")
+    with (gzip.open(path, "wb") if gz else open(path, "wb")) as fh:
+        fh.write(data)
+
+
+CASES = {
+    "fastq4": "@r1 c\nACGTAAAACGT\n+\nIIIIIIIIIII\n@r2\nTTTTGGGGACCA\n+r2\nIIIIIIIIIIII\n",
+    "crlf": "@r1\r\nACGTAAAACGT\r\n+\r\nIIIIIIIIIII\r\n@r2\r\nTTTT\r\n+\r\nIIII\r\n",
+    "fasta_multiline": ">s1 desc\nACGT\nAAAA\n\nCCCC\n>s2\nGG\n>empty\n>s3\nTTTTT",
+    "mixed": ">fa\nACGTACGT\n@fq\nAAAA\nCCCC\n+\nIIII\nIIII\n>fb\nGGGG\n",
+    "truncated_quality": "@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nAAAACCCC\n+\nIII\n",
+    "missing_quality": "@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nAAAACCCC\n+",
+    "qual_mismatch_then_more": "@r1\nACGT\n+\nIIIII\n@r2\nAAAA\n+\nIIII\n",
+    "leading_garbage": "garbage line\n\n@r1\nACGT\n+\nIIII\n",
+    "quality_starting_with_at": "@r1\nACGTACGT\n+\n@IIIIIII\n@r2\nCCCC\n+\n@@@@\n",
+    "no_trailing_newline": "@r1\nACGT\n+\nIIII",
+    "lone_cr_line": ">x\n\r\nACGT\n",
+    "empty_file": "",
+    "only_marker": "@",
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("gz", [False, True])
+def test_reader_matches_oracle_parser(tmp_path, name, gz):
+    path = str(tmp_path / (name + (".gz" if gz else ".txt")))
+    _write(path, CASES[name], gz)
+    got, n = tj.read_file_stream(path)
+    exp, m = orc.parse_file_to_stream(path)
+    assert n == m and got.tobytes() == exp.tobytes()
+
+
+def test_reader_known_streams(tmp_path):
+    p = str(tmp_path / "a.fq")
+    _write(p, CASES["fastq4"])
+    s, n = tj.read_file_stream(p)
+    assert n == 2 and s.tobytes() == b"ACGTAAAACGT\nTTTTGGGGACCA\n"
+    _write(p, CASES["fasta_multiline"])
+    s, n = tj.read_file_stream(p)
+    assert n == 4 and s.tobytes() == b"ACGTAAAACCCC\nGG\n\nTTTTT\n"
+    _write(p, CASES["truncated_quality"])
+    s, n = tj.read_file_stream(p)
+    assert n == 1 and s.tobytes() == b"ACGTACGT\n"       # the bad record ends the file (reference loop `>= 0`)
+    _write(p, CASES["crlf"])
+    s, n = tj.read_file_stream(p)
+    assert s.tobytes() == b"ACGTAAAACGT\nTTTT\n"
+    with pytest.raises(FileNotFoundError):
+        tj.read_file_stream(str(tmp_path / "missing.fq"))
+
+
+def test_reader_large_blocks(tmp_path):
+    # records straddling the 4 MiB read blocks, and a long multi-line FASTA record
+    rng = np.random.default_rng(5)
+    reads = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 400)))) for _ in range(40000)]
+    txt = "".join(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" for i, r in enumerate(reads))
+    long_seq = "".join(rng.choice(list("ACGT"), size=300000))
+    txt += ">long\n" + "\n".join(long_seq[i:i + 70] for i in range(0, len(long_seq), 70)) + "\n"
+    p = str(tmp_path / "big.fq.gz")
+    _write(p, txt, gz=True)
+    s, n = tj.read_file_stream(p)
+    assert n == len(reads) + 1 and s.tobytes() == ("\n".join(reads) + "\n" + long_seq + "\n").encode()
+    e, m = orc.parse_file_to_stream(p)
+    assert m == n and e.tobytes() == s.tobytes()
+
+
+def test_fixture_file_stream(golden_dir, known_answers):
+    s, n = tj.read_file_stream(os.path.join(golden_dir, "err1750956.fastq.gz"))
+    f = known_answers["file"]
+    assert n == f["n_reads"] and s.size == f["n_bases"] + f["n_reads"]
+
+
+def test_synth_stream_properties():
+    a = tj.synth_stream(5000, 150, 200000, n_threads=1)
+    b = tj.synth_stream(5000, 150, 200000, n_threads=4)
+    assert a.tobytes() == b.tobytes() and a.size == 5000 * 151
+    m = a.reshape(5000, 151)
+    assert (m[:, 150] == 10).all() and np.isin(m[:, :150], np.frombuffer(b"ACGT", np.uint8)).all()
+    # both strands occur and reads of one strand are substrings of the genome implied by the other reads' overlaps:
+    # cheap proxy -- the oracle finds tracts on both strands and the strand filter keeps most contexts
+    o = orc.Oracle(10)
+    o.scan_stream(a, 3)
+    raw = o.c.n_elem
+    assert 5.0 < raw / 5000 < 7.0                               # r-bar ~ 5.97
+    # ragged reads and per-sample variants
+    r = tj.synth_stream(300, 2000, 500000, read_len_max=20000, n_threads=3)
+    lens = np.diff(np.flatnonzero(np.concatenate(([True], r == 10)))) - 1
+    lens[0] += 1
+    assert lens.min() >= 2000 and lens.max() <= 20000 and len(lens) == 300
+    v1 = tj.synth_stream(2000, 150, 200000, variant_seed=1)
+    v2 = tj.synth_stream(2000, 150, 200000, variant_seed=2)
+    assert v1.tobytes() != v2.tobytes() and v1.tobytes() != a[:v1.size].tobytes()

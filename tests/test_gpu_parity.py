@@ -1,0 +1,384 @@
+"""Parity of the HIP path with the CPU oracle, through the C ABI (every test needs an MI355X: -m gpu).
+
+Bit-exact everywhere: the path is integer/byte work.  Raw records are compared as multisets (their order is
+irrelevant before the sort -- reference: src/hopo_counter.c:351), located records in emission order, and the
+finalised arrays byte for byte (all 40 bytes of every hopo_element, the index ranges and the coverage)."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import tatajuba_amd as tj
+from oracle import orc
+from tests.pyref import scan_closed_form
+
+pytestmark = pytest.mark.gpu
+
+
+def rec_sorted(a):
+    a = np.ascontiguousarray(a)
+    o = np.lexsort((a["meta"], a["ctx1"], a["ctx0"]))
+    return a[o]
+
+
+def oracle_raw(stream, k, m):
+    o = orc.Oracle(k)
+    o.scan_stream(stream, m)
+    return o
+
+
+def as_records(elems):
+    r = np.zeros(len(elems), dtype=tj.RECORD_DTYPE)
+    for f in ("ctx0", "ctx1", "meta"):
+        r[f] = elems[f]
+    return r
+
+
+def check_raw_multiset(stream, k, m):
+    stream = np.frombuffer(stream, np.uint8) if not isinstance(stream, np.ndarray) else stream
+    c = tj.Counter(k)
+    c.scan_host(stream, m)
+    got = c.download_raw()
+    o = oracle_raw(stream, k, m)
+    exp = as_records(o.elems())
+    assert len(got) == len(exp), (len(got), len(exp))
+    assert (rec_sorted(got) == rec_sorted(exp)).all()
+    assert c.undefined_runs() == o.c.n_undefined
+    c.close()
+    return len(got)
+
+
+def check_finalise(stream_parts, k, m, remove_biased, min_cov):
+    """stream_parts: list of uint8 arrays scanned one after the other into the same counter"""
+    c = tj.Counter(k)
+    o = orc.Oracle(k)
+    for s in stream_parts:
+        c.scan_host(s, m)
+        o.scan_stream(s, m)
+    assert c.raw_count() == o.c.n_elem
+    st = c.finalise(remove_biased, min_cov)
+    o.finalise(remove_biased, min_cov)
+    assert st == o.c.status
+    if st in (1, 2):
+        c.close()
+        return st, 0
+    got, exp = c.download_kept(), o.elems() if st == 0 else None
+    if st == 0:
+        assert c.n_kept == o.c.n_elem and got.tobytes() == exp.tobytes()
+        gi, gf = c.download_idx()
+        ei, ef = o.idx()
+        assert c.n_idx == o.c.n_idx and (gi == ei).all() and (gf == ef).all()
+        assert c.coverage == o.c.coverage
+    n = c.n_kept
+    c.close()
+    return st, n
+
+
+# ---- known answers through the drop-in CPU entry ------------------------------------------------------------------
+
+def test_known_answers_update_from_seq(known_answers):
+    for case in known_answers["scan"]:
+        h = tj.HopoCounter.new(case["k"])
+        h.update_from_seq(case["seq"], case["m"])
+        e = h.elems()
+        d = tj.decode_meta(e["meta"])
+        got = [(int(d["base"][i]), int(d["length"][i]), int(e["read_offset"][i]), int(d["canon_flag"][i]),
+                int(e["ctx0"][i]), int(e["ctx1"][i])) for i in range(len(e))]
+        exp = [(r[0], r[1], r[2], r[3], int(r[4], 16), int(r[5], 16)) for r in case["records"]]
+        assert got == exp, case["seq"]
+        assert (d["count"] == 1).all() and (d["mismatches"] == -2).all() and (e["loc_pos"] == -1).all()
+        o = orc.Oracle(case["k"])
+        o.scan_seq(case["seq"], case["m"])
+        assert e.tobytes() == o.elems().tobytes()          # all 40 bytes of every element
+        h.delete()
+
+
+def test_stale_context_and_undefined(known_answers):
+    c0, c1 = known_answers["stale_context"]
+    h = tj.HopoCounter.new(c0["k"])
+    h.update_from_seq(c0["seq"], c0["m"])
+    o = orc.Oracle(c0["k"])
+    o.scan_seq(c0["seq"], c0["m"])
+    assert h.c.n_elem == c0["n_records"] and h.elems().tobytes() == o.elems().tobytes()
+    h.delete()
+    c = tj.Counter(c1["k"])
+    assert len(c.scan_host_located((c1["seq"] + "\n").encode(), c1["m"])) == 0
+    c.close()
+
+
+def test_update_from_seq_appends_and_m2_rescan():
+    # the reference rescans reference windows with m = 2 (src/genome_set.c:539)
+    h = tj.HopoCounter.new(4)
+    o = orc.Oracle(4)
+    for seq in ("ACGTAACCGGTTACGTACGT", "TTGACCCCAGTAAGTC", "ACG", "ACGTTTTTTTTTTACGTAC"):
+        h.update_from_seq(seq, 2)
+        o.scan_seq(seq, 2)
+    assert h.c.n_elem == o.c.n_elem > 3 and h.elems().tobytes() == o.elems().tobytes()
+    h.delete()
+
+
+# ---- random strings: located records in emission order, every alphabet quirk --------------------------------------
+
+def test_random_reads_located_order():
+    rng = random.Random(99)
+    alphabets = ["ACGT", "ACGT", "AC", "ACGTN", "ACGTacgtUN-", "AT", "ACGTNNN"]
+    for k, m in [(3, 3), (2, 1), (5, 2), (10, 3), (16, 4), (25, 4), (31, 3), (32, 6)]:
+        reads = []
+        for it in range(400):
+            ab = alphabets[it % len(alphabets)]
+            L = rng.randint(0, 260)
+            s = []
+            while len(s) < L:
+                s.extend(rng.choice(ab) * rng.choice([1, 1, 1, 2, 3, 4, 5, 9, 40]))
+            reads.append("".join(s[:L]))
+        stream = ("\n".join(reads) + "\n").encode("latin-1")
+        c = tj.Counter(k)
+        loc = c.scan_host_located(stream, m)
+        starts = np.cumsum([0] + [len(r) + 1 for r in reads])
+        exp = []
+        for r, st in zip(reads, starts):
+            for (base, n, off, flag, c0, c1) in scan_closed_form(r, k, m):
+                meta = base | ((n & 0x3ff) << 2) | (1 << 12) | (0xffe << 32) | (flag << 49)
+                exp.append((c0, c1, meta, st + off + k))
+        got = [(int(x["ctx0"]), int(x["ctx1"]), int(x["meta"]), int(x["pos"])) for x in loc]
+        assert got == exp, (k, m)
+        o = oracle_raw(np.frombuffer(stream, np.uint8), k, m)
+        assert len(got) == o.c.n_elem
+        c.close()
+
+
+# ---- raw multiset parity -----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("k,m", [(10, 3), (15, 4), (25, 4), (2, 1), (32, 5), (7, 2)])
+def test_raw_fixture_file(golden_dir, known_answers, k, m):
+    s, n = tj.read_file_stream(os.path.join(golden_dir, "err1750956.fastq.gz"))
+    nrec = check_raw_multiset(s, k, m)
+    for case in known_answers["file"]["cases"]:
+        if (case["k"], case["m"]) == (k, m):
+            assert nrec == case["raw"]
+
+
+@pytest.mark.parametrize("k,m,L", [(10, 3, 150), (15, 4, 150), (25, 4, 150), (10, 3, 37), (4, 2, 9)])
+def test_raw_synthetic_short_reads(k, m, L):
+    s = tj.synth_stream(20000, L, 300000)
+    check_raw_multiset(s, k, m)
+
+
+def test_raw_long_ragged_reads_and_tile_edges():
+    s = tj.synth_stream(300, 2000, 400000, read_len_max=20000)
+    check_raw_multiset(s, 25, 4)
+    check_raw_multiset(s, 10, 3)
+    # tracts longer than the right halo, longer than a tile, wrapping the 10-bit length, at every alignment
+    rng = np.random.default_rng(3)
+    parts = []
+    for i in range(60):
+        pre = "".join(rng.choice(list("ACGT"), size=int(rng.integers(30, 5000))))
+        run = "ACGTN"[i % 5] * int([3, 17, 190, 193, 400, 511, 512, 600, 4095, 4096, 4097, 9000][i % 12])
+        post = "".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 70))))
+        parts.append(pre + run + post)
+    stream = ("\n".join(parts) + "\n").encode()
+    for k, m in [(3, 3), (10, 3), (32, 4)]:
+        check_raw_multiset(stream, k, m)
+
+
+def test_raw_edge_streams():
+    for stream in [b"", b"\n", b"\n\n\n", b"ACGT", b"ACGTAAAACGTA", b"ACGTAAAACGTA\n", b"A" * 5000 + b"\n",
+                   b"ACG\n" * 3000, b"AAAA\nCCCC\nGGGG\n", b"ACGTTTTTACGT\n\nACGTTTTTACGT\n",
+                   b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN\n" * 10, b"ACGAAAACGTNNNNACGTNNNNNACGT\nACGNNNNACGT\n"]:
+        a = np.frombuffer(stream, np.uint8)
+        if a.size == 0:
+            c = tj.Counter(3)
+            c.scan_host(a, 3)
+            assert c.raw_count() == 0
+            c.close()
+            continue
+        check_raw_multiset(a, 3, 3)
+        check_raw_multiset(a, 2, 2)
+
+
+def test_scan_device_pointer_api_and_multiple_batches():
+    torch = pytest.importorskip("torch")
+    s = tj.synth_stream(30000, 150, 300000)
+    t = torch.from_numpy(s.copy()).cuda()
+    c = tj.Counter(10)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    half = (s.size // 2 // 151) * 151                    # whole reads, 16-byte aligned start for the 2nd half? no:
+    half = (half // (151 * 16)) * (151 * 16)             # multiple of 16 bytes and of whole reads
+    c.scan_device(t.data_ptr(), half, 3)
+    c.scan_device(t.data_ptr() + half, s.size - half, 3)
+    got = c.download_raw()
+    exp = as_records(oracle_raw(s, 10, 3).elems())
+    assert (rec_sorted(got) == rec_sorted(exp)).all()
+    assert c.last_scan_ms() > 0
+    with pytest.raises(tj.TatajubaAmdError, match="aligned"):
+        c.scan_device(t.data_ptr() + 3, 100, 3)
+    c.close()
+
+
+# ---- finalise: byte-identical elem[], idx_initial/final, coverage --------------------------------------------------
+
+@pytest.mark.parametrize("case", range(4))
+def test_finalise_fixture_cases(golden_dir, known_answers, case):
+    f = known_answers["file"]
+    cs = f["cases"][case]
+    s, _ = tj.read_file_stream(os.path.join(golden_dir, f["path"]))
+    st, n = check_finalise([s], cs["k"], cs["m"], cs["remove_biased"], cs["min_coverage"])
+    assert st == 0 and n == cs["n_elem"]
+    st, n = check_finalise([s, s], cs["k"], cs["m"], cs["remove_biased"], cs["min_coverage"])   # "paired"
+    assert st == 0
+
+
+@pytest.mark.parametrize("k,m,rb,mc", [(10, 3, 1, 5), (10, 3, 0, 5), (15, 4, 1, 5), (25, 4, 1, 5), (25, 4, 0, 0),
+                                       (2, 1, 1, 0), (32, 4, 1, 3)])
+def test_finalise_synthetic(k, m, rb, mc):
+    s = tj.synth_stream(20000, 150, 100000)              # depth 30: most tracts seen on both strands
+    st, n = check_finalise([s], k, m, rb, mc)
+    assert st == 0 and n > 0
+
+
+def test_finalise_statuses_and_count_semantics():
+    assert check_finalise([np.frombuffer(b"ACGT\n", np.uint8)], 3, 3, 1, 5)[0] == 1
+    assert check_finalise([np.frombuffer(b"CCGAAAAGAT\n", np.uint8)], 3, 3, 1, 0)[0] == 2
+    assert check_finalise([np.frombuffer(b"CCGAAAAGAT\nATCTTTTCGG\n", np.uint8)], 3, 3, 1, 5)[0] == 3
+    assert check_finalise([np.frombuffer(b"CCGAAAAGAT\nATCTTTTCGG\n", np.uint8)], 3, 3, 1, 2) == (0, 1)
+    assert check_finalise([np.frombuffer(b"CCGAAAAGAT\nCCGAAAAGAT\nCCGCCCCGAT\n", np.uint8)], 3, 3, 0, 0) == (0, 1)
+    # signed 10-bit length order: a 600-base tract stores -424 and sorts after the short ones
+    s = ("AC" + "G" * 600 + "AC\n" + "GT" + "C" * 600 + "GT\n" + "ACGGGAC\nGTCCCGT\n").encode()
+    assert check_finalise([np.frombuffer(s, np.uint8)], 2, 3, 1, 0)[0] == 0
+    # 20-bit count wrap: 2^19 copies of the same tract on each strand -> count 2^20 wraps to 0
+    one = np.frombuffer(b"CCGAAAAGAT\nATCTTTTCGG\n", np.uint8)
+    big = np.tile(one, 1 << 19)
+    st, n = check_finalise([big, np.frombuffer(b"TTGCCCCAGT\nACTGGGGCAA\n", np.uint8)], 3, 3, 1, 0)
+    assert st == 0 and n == 2
+
+
+# ---- the drop-in file API -----------------------------------------------------------------------------------------
+
+def test_dropin_from_file_single_and_paired(golden_dir, known_answers):
+    f = known_answers["file"]
+    path = os.path.join(golden_dir, f["path"])
+    for cs in f["cases"]:
+        opt = tj.Options.defaults(cs["k"], cs["m"], cs["min_coverage"], bool(cs["remove_biased"]))
+        h = tj.HopoCounter.new_or_append_from_file(None, path, opt)
+        assert h.c.n_elem == cs["raw"] and h.c.name == path.encode() and h.c.opt.kmer_size == cs["k"]
+        h.finalise()
+        o = orc.Oracle(cs["k"])
+        o.scan_file(path, cs["m"])
+        o.finalise(cs["remove_biased"], cs["min_coverage"])
+        assert (h.c.n_elem, h.c.n_alloc, h.c.n_idx, h.c.coverage) == (cs["n_elem"], cs["n_elem"], cs["n_idx"], cs["coverage"])
+        assert h.elems().tobytes() == o.elems().tobytes()
+        gi, gf = h.idx()
+        ei, ef = o.idx()
+        assert (gi == ei).all() and (gf == ef).all()
+        h.delete()
+    # paired: R2 appended into the same counter (reference: src/genome_set.c:72-73)
+    opt = tj.Options.defaults(10, 3, 5, True, paired_end=True)
+    h = tj.HopoCounter.new_or_append_from_file(None, path, opt)
+    tj.HopoCounter.new_or_append_from_file(h, path, opt)
+    assert h.c.n_elem == f["paired_same_file_twice_k10_m3"]["raw"]
+    h.finalise()
+    assert h.c.n_elem == f["paired_same_file_twice_k10_m3"]["n_elem"]
+    o = orc.Oracle(10)
+    o.scan_file(path, 3); o.scan_file(path, 3)
+    o.finalise(1, 5)
+    assert h.elems().tobytes() == o.elems().tobytes() and h.c.coverage == o.c.coverage
+    h.delete()
+
+
+def test_dropin_mixed_host_and_device_records(tmp_path):
+    p = str(tmp_path / "r.fa")
+    reads = ["TTCCGAAAAGATTT", "TTATCTTTTCGGTT", "GGCCGAAAAGATGG", "ACGTACGT"]
+    open(p, "w").write("".join(f">r{i}\n{r}\n" for i, r in enumerate(reads)))
+    opt = tj.Options.defaults(3, 3, 0, True)
+    h = tj.HopoCounter.new_or_append_from_file(None, p, opt)
+    h.update_from_seq("AAATCTTTTCGGAA", 3)
+    o = orc.Oracle(3)
+    for r in reads + ["AAATCTTTTCGGAA"]:
+        o.scan_seq(r, 3)
+    assert h.c.n_elem == o.c.n_elem
+    h.finalise()
+    o.finalise(1, 0)
+    assert h.elems().tobytes() == o.elems().tobytes() and h.c.coverage == o.c.coverage
+    h.delete()
+
+
+def test_dropin_large_file_batches(tmp_path):
+    # > 64 MiB of sequence so that the double-buffered batching is exercised
+    s = tj.synth_stream(600000, 150, 2000000)
+    p = str(tmp_path / "big.fa")
+    with open(p, "wb") as fh:
+        m = s.reshape(-1, 151)
+        hdr = np.frombuffer(b">r\n", np.uint8)
+        out = np.empty((m.shape[0], 3 + 151), np.uint8)
+        out[:, :3] = hdr
+        out[:, 3:] = m
+        fh.write(out.tobytes())
+    opt = tj.Options.defaults(10, 3, 5, True)
+    h = tj.HopoCounter.new_or_append_from_file(None, p, opt)
+    o = orc.Oracle(10)
+    o.scan_stream(s, 3)
+    assert h.c.n_elem == o.c.n_elem
+    h.finalise()
+    o.finalise(1, 5)
+    assert h.elems().tobytes() == o.elems().tobytes() and h.c.coverage == o.c.coverage
+    gi, gf = h.idx()
+    ei, ef = o.idx()
+    assert (gi == ei).all() and (gf == ef).all()
+    h.delete()
+
+
+# ---- full benchmark size: size-independent properties ---------------------------------------------------------------
+
+def _revcomp_stream(s, L):
+    m = s.reshape(-1, L + 1)
+    lut = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        lut[a] = b
+    r = np.empty_like(m)
+    r[:, :L] = lut[m[:, L - 1::-1]] if L > 0 else m[:, :0]
+    r[:, L] = 10
+    return r.reshape(-1)
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 (10 M x 150 bp, k=10 m=3): properties that need no CPU pass at full size."""
+    n_reads, L, k, m = 10_000_000, 150, 10, 3
+    s = tj.synth_stream(n_reads, L, 5_000_000, n_threads=16)
+    c = tj.Counter(k)
+    c.scan_host(s, m)
+    raw = c.raw_count()
+    assert 5.8 < raw / n_reads < 6.15                          # r-bar ~ 5.97
+    assert c.finalise(1, 5) == 0
+    kept = c.download_kept()
+    d = tj.decode_meta(kept["meta"])
+    key = np.stack([d["base"].astype(np.uint64), kept["ctx0"], kept["ctx1"], d["length"].astype(np.uint64)], 1)
+    # sortedness: strictly decreasing (base, ctx0, ctx1, length)
+    a, b = key[:-1], key[1:]
+    gt = np.zeros(len(a), bool)
+    eq = np.ones(len(a), bool)
+    for j in range(4):
+        gt |= eq & (a[:, j] > b[:, j])
+        eq &= a[:, j] == b[:, j]
+    assert gt.all()
+    assert (d["canon_flag"] == 3).all() and (d["count"] >= 2).all() and int(d["count"].sum()) <= raw
+    gi, gf = c.download_idx()
+    assert (gi < gf).all() and (gf[:-1] <= gi[1:]).all() and gf[-1] <= len(kept)
+    cov = c.coverage
+    # a 1/16 sample agrees with the oracle exactly
+    sub = s[: (n_reads // 16) * (L + 1)]
+    check_finalise([sub], k, m, 1, 5)
+    # linearity: scanning the stream twice doubles every count and keeps the keys
+    c.reset()
+    c.scan_host(s, m); c.scan_host(s, m)
+    assert c.raw_count() == 2 * raw and c.finalise(1, 5) == 0
+    k2 = c.download_kept()
+    d2 = tj.decode_meta(k2["meta"])
+    assert (k2["ctx0"] == kept["ctx0"]).all() and (k2["ctx1"] == kept["ctx1"]).all() and (d2["count"] == 2 * d["count"]).all()
+    assert c.coverage == 2 * cov
+    # strand symmetry: reverse-complementing every read gives the same histogram
+    c.reset()
+    c.scan_host(_revcomp_stream(s, L), m)
+    assert c.raw_count() == raw and c.finalise(1, 5) == 0
+    assert c.download_kept().tobytes() == kept.tobytes() and c.coverage == cov
+    c.close()
