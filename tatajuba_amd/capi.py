@@ -86,6 +86,31 @@ EXPORTS = [
 ]
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch's wheel bundles its own libamdhip64.so (soname libamdhip64.so.7, the same
+    soname our library needs); if ours pulled in /opt/rocm's copy first, a later `import torch` would load a second
+    runtime and see no GPU.  So when torch is installed, map its copy first (without importing torch) and let the
+    dynamic loader bind libtatajuba_amd.so to it by soname.  TATAJUBA_AMD_HIP_RUNTIME=system skips this."""
+    if os.environ.get("TATAJUBA_AMD_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _LIB
     if _LIB is not None:
@@ -93,6 +118,7 @@ def lib():
     path = library_path()
     if not os.path.exists(path):
         build_library()
+    _share_hip_runtime_with_torch()
     L = C.CDLL(path)
     P = C.POINTER(_HopoCounterStruct)
     L.new_hopo_counter.restype = P; L.new_hopo_counter.argtypes = [C.c_int]

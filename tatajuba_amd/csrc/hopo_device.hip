@@ -145,11 +145,29 @@ __device__ __forceinline__ bool byte_is_acgtu (u32 b)
 
 __device__ __forceinline__ u32 byte_code (u32 b) { return byte_is_acgtu (b) ? (((b >> 1) ^ (b >> 2)) & 3u) : 0u; }
 
-// canonical record fields from the two flanks as read (reference: src/hopo_counter.c:233-246)
-__device__ __forceinline__ void canonicalise (u64 left, u64 right, u32 cb, int k, u64 &c0, u64 &c1, u32 &base, u32 &flag)
+// bit i of x -> bits 2i and 2i+1 (both set)
+__device__ __forceinline__ u64 spread_pairs (u32 x)
+{
+  u64 v = x;
+  v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  v = (v | (v << 2)) & 0x3333333333333333ull;
+  v = (v | (v << 1)) & 0x5555555555555555ull;
+  return v | (v << 1);
+}
+
+// canonical record fields from the two flanks as read (reference: src/hopo_counter.c:233-246).  linv / rinv mark the
+// non-ACGTU flank positions (k-bit masks): the reference's table gives them 4 in BOTH columns, so they pack as 0 in the
+// reverse-complemented orientation too -- force their forward code to 3 before complementing.
+__device__ __forceinline__ void canonicalise (u64 left, u64 right, u32 linv, u32 rinv, u32 cb, int k,
+                                              u64 &c0, u64 &c1, u32 &base, u32 &flag)
 {
   if (cb < 2u) { c0 = left; c1 = right; base = cb; flag = 1u; }
-  else { c0 = revcomp_k (right, k); c1 = revcomp_k (left, k); base = 3u - cb; flag = 2u; }
+  else {
+    if (linv | rinv) { left |= spread_pairs (linv); right |= spread_pairs (rinv); }
+    c0 = revcomp_k (right, k); c1 = revcomp_k (left, k); base = 3u - cb; flag = 2u;
+  }
 }
 
 __device__ __forceinline__ u64 make_meta (u32 base, long len, u32 flag)
@@ -158,14 +176,16 @@ __device__ __forceinline__ u64 make_meta (u32 base, long len, u32 flag)
 }
 
 // Slow path from global memory for a run [gs, ge] of a valid base: both flanks present?  then build the flanks.
-__device__ bool flanks_from_stream (const uint8_t *seq, long n, long gs, long ge, int k, u64 &left, u64 &right)
+__device__ bool flanks_from_stream (const uint8_t *seq, long n, long gs, long ge, int k, u64 &left, u64 &right, u32 &linv, u32 &rinv)
 {
-  left = right = 0;
+  left = right = 0; linv = rinv = 0;
   for (int i = 0; i < k; i++) {
     u32 bl = stream_byte (seq, n, gs - k + i), br = stream_byte (seq, n, ge + 1 + i);
     if (bl == '\n' || br == '\n') return false;
     left |= (u64) byte_code (bl) << (2 * i);
     right |= (u64) byte_code (br) << (2 * i);
+    linv |= (byte_is_acgtu (bl) ? 0u : 1u) << i;
+    rinv |= (byte_is_acgtu (br) ? 0u : 1u) << i;
   }
   return true;
 }
@@ -284,7 +304,7 @@ void scan_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, i
         bool ok;
         long len;
         u64 left = 0, right = 0;
-        u32 cb = 0;
+        u32 cb = 0, linv = 0, rinv = 0;
         if (e >= 0 && e + k < TJ_WIN) {             // everything needed is in LDS
           len = e - s + 1;
           ok = ((bits64 (s_sent, s - k) & kbits) == 0ull) && ((bits64 (s_sent, e + 1) & kbits) == 0ull);
@@ -292,6 +312,7 @@ void scan_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, i
             left = bits64 (s_code, 2 * (s - k)) & km;
             right = bits64 (s_code, 2 * (e + 1)) & km;
             cb = (s_code[s >> 4] >> (2 * (s & 15))) & 3u;
+            if (cb >= 2u) { linv = (u32) (bits64 (s_inval, s - k) & kbits); rinv = (u32) (bits64 (s_inval, e + 1) & kbits); }
           }
         }
         else {                                      // tract runs past the window: walk the stream (rare)
@@ -299,13 +320,13 @@ void scan_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, i
           long ge = gs;
           while (stream_byte (seq, n_bytes, ge + 1) == b) ge++;
           len = ge - gs + 1;
-          ok = flanks_from_stream (seq, n_bytes, gs, ge, k, left, right);
+          ok = flanks_from_stream (seq, n_bytes, gs, ge, k, left, right, linv, rinv);
           cb = byte_code (b);
         }
         if (ok) {
           if (!inval) {
             u32 base, flag;
-            canonicalise (left, right, cb, k, c0, c1, base, flag);
+            canonicalise (left, right, linv, rinv, cb, k, c0, c1, base, flag);
             meta = make_meta (base, len, flag);
             pos = (u64) gs;
             have = true;
@@ -336,7 +357,7 @@ __global__ void nrun_fixup_kernel (const uint8_t *__restrict__ seq, long n_bytes
     const long gs = fix[i].pos;
     bool found = false;
     u64 left = 0, right = 0;
-    u32 cb = 0;
+    u32 cb = 0, linv = 0, rinv = 0;
     long p = gs - 1;
     while (p >= 0 && seq[p] != '\n') {
       const u32 b = seq[p];
@@ -344,14 +365,14 @@ __global__ void nrun_fixup_kernel (const uint8_t *__restrict__ seq, long n_bytes
       while (q - 1 >= 0 && seq[q - 1] == b) q--;       // run [q, p]
       if (byte_is_acgtu (b) && (p - q + 1) >= mprime) {
         // recorded iff k bases of the same read precede it (its right side is fine: it ends before our run does)
-        if (flanks_from_stream (seq, n_bytes, q, p, k, left, right)) { found = true; cb = byte_code (b); }
+        if (flanks_from_stream (seq, n_bytes, q, p, k, left, right, linv, rinv)) { found = true; cb = byte_code (b); }
         break;                                          // an earlier run would start even closer to the read start
       }
       p = q - 1;
     }
     if (found) {
       u64 c0, c1; u32 base, flag;
-      canonicalise (left, right, cb, k, c0, c1, base, flag);
+      canonicalise (left, right, linv, rinv, cb, k, c0, c1, base, flag);
       u64 idx = atomicAdd (&ctr->n_rec, 1ull);
       if (idx < cap) store_record<W> (out, idx, c0, c1, make_meta (base, fix[i].len, flag), (u64) gs);
       else ctr->overflow = 1u;
