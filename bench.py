@@ -86,6 +86,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # raw record count of the sample (the aggregation consumes the raw records, so count them once, untimed)
+    c.reset()
+    c.scan_device(dev.data_ptr(), n_bytes, m)
+    raw = c.raw_count()
     for _ in range(args.warmup):
         step()
     fence()
@@ -101,7 +105,6 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    raw = c.raw_count()
     kept = c.n_kept
     scan_avg = float(np.mean(scan_ms))
     fin_avg = float(np.mean(fin_ms))

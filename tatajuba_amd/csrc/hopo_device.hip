@@ -60,22 +60,32 @@ extern "C" int tjamd_device_count (void)
 // ---------------------------------------------------------------------------------------------------------------
 // geometry of the scan tile
 
-#define TJ_BLOCK   256
-#define TJ_TILE    4096                 // bytes of stream owned by one workgroup iteration
 #define TJ_HL      64                   // left halo  (>= max k + 1, multiple of 32)
 #define TJ_HR      192                  // right halo (tracts whose end + k stays inside are handled from LDS)
-#define TJ_WIN     (TJ_HL + TJ_TILE + TJ_HR)     // 4352
-#define TJ_NCHUNK  (TJ_WIN / 16)                 // 272 chunks of 16 bytes
-#define TJ_MASKW   (TJ_WIN / 32 + 4)             // words per bit-plane (+ zeroed pad for 3-word funnel reads)
-#define TJ_CODEW   (TJ_WIN / 16 + 4)             // words of 2-bit codes (+ pad)
-#define TJ_MAXCAND (TJ_TILE / 2)                 // tracts have >= 2 bases, so at most one candidate per 2 bytes
+
+template <int BLOCK, int TILE>
+struct TileLds
+{
+  static constexpr int WIN = TJ_HL + TILE + TJ_HR;       // bytes of stream seen by one tile
+  static constexpr int NCHUNK = WIN / 16;                // 16-byte chunks
+  static constexpr int MASKW = WIN / 32 + 4;             // words per bit-plane (+ zeroed pad for 3-word funnel reads)
+  static constexpr int CODEW = WIN / 16 + 4;             // words of 2-bit codes (+ pad)
+  static constexpr int MAXCAND = TILE / 2;               // tracts have >= 2 bases: at most one candidate per 2 bytes
+  static constexpr int NLOAD = (NCHUNK + BLOCK - 1) / BLOCK;
+  u32 code[CODEW];
+  u32 start[MASKW];
+  u32 sent[MASKW];
+  u32 inval[MASKW];
+  unsigned short cand[MAXCAND];
+  u32 ncand;
+};
 
 struct DevCounters
 {
-  u64 n_rec;        // records appended to the output list
-  u64 n_fix;        // pending non-ACGTU runs (see nrun_fixup_kernel)
+  u64 n_rec;        // records appended to the located list
+  u64 n_fix;        // pending non-ACGTU runs (see nrun_fixup kernels)
   u64 n_undefined;  // qualifying non-ACGTU runs without an earlier tract in the read (reference: uninitialised memory)
-  u32 overflow;     // output list too small
+  u32 overflow;     // output list / a bucket too small
   u32 fix_overflow; // fix list too small
 };
 
@@ -217,105 +227,127 @@ __device__ __forceinline__ void emit_record (bool have, u64 c0, u64 c1, u64 meta
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// scan kernel.  W = 3: 24-byte records; W = 4: located records (adds the stream position of the tract's first base).
+// tile scan, shared by both kernels.  The sink receives, once per round and from every thread of the workgroup
+// (wave- and block-uniform call), at most one tract: (have, ctx0, ctx1, base, 10-bit length, strand flag, position).
 
-template <int W>
-__global__ __launch_bounds__ (TJ_BLOCK)
-void scan_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
-                  u64 *__restrict__ out, u64 cap, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
+__device__ __forceinline__ void load_chunk (const uint8_t *__restrict__ seq, long n_bytes, long g, uint4 &v, u32 &prev)
 {
-  __shared__ u32 s_code[TJ_CODEW];
-  __shared__ u32 s_start[TJ_MASKW];
-  __shared__ u32 s_sent[TJ_MASKW];
-  __shared__ u32 s_inval[TJ_MASKW];
-  __shared__ unsigned short s_cand[TJ_MAXCAND];
-  __shared__ u32 s_ncand;
+  if (g >= 0 && g + 16 <= n_bytes) v = *reinterpret_cast<const uint4 *> (seq + g);
+  else {                                                // chunk straddles the ends of the stream (first / last tile only)
+    u64 lo = 0, hi = 0;
+#pragma unroll 1
+    for (int b = 0; b < 8; b++) {
+      lo |= (u64) stream_byte (seq, n_bytes, g + b) << (8 * b);
+      hi |= (u64) stream_byte (seq, n_bytes, g + 8 + b) << (8 * b);
+    }
+    v.x = (u32) lo; v.y = (u32) (lo >> 32); v.z = (u32) hi; v.w = (u32) (hi >> 32);
+  }
+  prev = stream_byte (seq, n_bytes, g - 1);
+}
 
+template <int BLOCK, int TILE, class Sink>
+__device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
+                                            TileLds<BLOCK, TILE> &T, Sink &sink, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
+{
+  typedef TileLds<BLOCK, TILE> G;
   const int tid = threadIdx.x;
   const u64 km = kmask (k);
-  const u64 kbits = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);   // k <= 32
+  const u64 kbits = (1ull << k) - 1ull;                 // k <= 32
 
-  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long g0 = tile * (long) TJ_TILE - TJ_HL;      // stream position of window byte 0 (may be negative)
+  uint4 pre[G::NLOAD];
+  u32 pprev[G::NLOAD];
+  long tile = blockIdx.x;
+  if (tile < n_tiles) {
+#pragma unroll
+    for (int i = 0; i < G::NLOAD; i++) {
+      const int c = tid + i * BLOCK;
+      if (c < G::NCHUNK) load_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, pre[i], pprev[i]);
+    }
+  }
 
-    // ---- phase 1: load + classify -------------------------------------------------------------------------
-    if (tid == 0) s_ncand = 0;
-    if (tid < 4) { s_code[TJ_CODEW - 4 + tid] = 0; s_start[TJ_MASKW - 4 + tid] = 0; s_sent[TJ_MASKW - 4 + tid] = 0xFFFFFFFFu; s_inval[TJ_MASKW - 4 + tid] = 0; }
-    for (int c = tid; c < TJ_NCHUNK; c += TJ_BLOCK) {
-      const long g = g0 + 16l * c;
-      u32 w[4];
-      if (g >= 0 && g + 16 <= n_bytes) {
-        uint4 v = *reinterpret_cast<const uint4 *> (seq + g);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-      }
-      else {
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const long g0 = tile * (long) TILE - TJ_HL;         // stream position of window byte 0 (may be negative)
+
+    // ---- phase 1: classify the prefetched chunks into LDS, then prefetch the next tile ------------------------
+    if (tid == 0) T.ncand = 0;
+    if (tid < 4) { T.code[G::CODEW - 4 + tid] = 0; T.start[G::MASKW - 4 + tid] = 0; T.sent[G::MASKW - 4 + tid] = 0xFFFFFFFFu; T.inval[G::MASKW - 4 + tid] = 0; }
+#pragma unroll
+    for (int i = 0; i < G::NLOAD; i++) {
+      const int c = tid + i * BLOCK;
+      if (c < G::NCHUNK) {
+        const u32 w[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+        u32 prev = pprev[i];
+        u32 code32 = 0, st16 = 0, se16 = 0, iv16 = 0;
+#pragma unroll
         for (int j = 0; j < 4; j++) {
-          u32 x = 0;
-          for (int b = 0; b < 4; b++) x |= stream_byte (seq, n_bytes, g + 4 * j + b) << (8 * b);
-          w[j] = x;
+          u32 c8, s4, e4, i4;
+          classify_word (w[j], prev, c8, s4, e4, i4);
+          code32 |= c8 << (8 * j); st16 |= s4 << (4 * j); se16 |= e4 << (4 * j); iv16 |= i4 << (4 * j);
+          prev = w[j] >> 24;
+        }
+        T.code[c] = code32;
+        reinterpret_cast<unsigned short *> (T.start)[c] = (unsigned short) st16;
+        reinterpret_cast<unsigned short *> (T.sent)[c] = (unsigned short) se16;
+        reinterpret_cast<unsigned short *> (T.inval)[c] = (unsigned short) iv16;
+      }
+    }
+    {
+      const long nt = tile + gridDim.x;
+      if (nt < n_tiles) {
+#pragma unroll
+        for (int i = 0; i < G::NLOAD; i++) {
+          const int c = tid + i * BLOCK;
+          if (c < G::NCHUNK) load_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, pre[i], pprev[i]);
         }
       }
-      u32 prev = stream_byte (seq, n_bytes, g - 1);
-      u32 code32 = 0, st16 = 0, se16 = 0, iv16 = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        u32 c8, s4, e4, i4;
-        classify_word (w[j], prev, c8, s4, e4, i4);
-        code32 |= c8 << (8 * j); st16 |= s4 << (4 * j); se16 |= e4 << (4 * j); iv16 |= i4 << (4 * j);
-        prev = w[j] >> 24;
-      }
-      s_code[c] = code32;
-      reinterpret_cast<unsigned short *> (s_start)[c] = (unsigned short) st16;
-      reinterpret_cast<unsigned short *> (s_sent)[c] = (unsigned short) se16;
-      reinterpret_cast<unsigned short *> (s_inval)[c] = (unsigned short) iv16;
     }
     __syncthreads ();
 
     // ---- phase 2: candidate tract starts among this lane's 16 positions ------------------------------------
     {
       const int p0 = TJ_HL + 16 * tid;
-      const u64 S = bits64 (s_start, p0);
+      const u64 S = bits64 (T.start, p0);
       u32 cand = (u32) S & 0xFFFFu;
       for (int j = 1; j < mprime; j++) cand &= ~(u32) (S >> j);     // next m'-1 positions continue the run
-      cand &= ~(u32) reinterpret_cast<unsigned short *> (s_sent)[p0 >> 4];  // a run of delimiters is not a tract
+      cand &= ~(u32) reinterpret_cast<unsigned short *> (T.sent)[p0 >> 4];  // a run of delimiters is not a tract
       if (cand) {
-        u32 at = atomicAdd (&s_ncand, (u32) __popc (cand));
-        while (cand) { int b = __ffs ((int) cand) - 1; cand &= cand - 1u; if (at < TJ_MAXCAND) s_cand[at] = (unsigned short) (p0 + b); at++; }
+        u32 at = atomicAdd (&T.ncand, (u32) __popc (cand));
+        while (cand) { int b = __ffs ((int) cand) - 1; cand &= cand - 1u; if (at < (u32) G::MAXCAND) T.cand[at] = (unsigned short) (p0 + b); at++; }
       }
     }
     __syncthreads ();
 
     // ---- phase 3: one lane per candidate --------------------------------------------------------------------
-    const int ncand = min ((int) s_ncand, TJ_MAXCAND);
-    for (int cb0 = 0; cb0 < ncand; cb0 += TJ_BLOCK) {
+    const int ncand = min ((int) T.ncand, G::MAXCAND);
+    for (int cb0 = 0; cb0 < ncand; cb0 += BLOCK) {
       const int ci = cb0 + tid;
       bool have = false;
-      u64 c0 = 0, c1 = 0, meta = 0, pos = 0;
+      u64 c0 = 0, c1 = 0, pos = 0;
+      u32 base = 0, flag = 0, len10 = 0;
       if (ci < ncand) {
-        const int s = s_cand[ci];
+        const int s = T.cand[ci];
         const long gs = g0 + s;
-        // run end: first run start after s
-        int e = -1;
-        for (int p = s + 1; p < TJ_WIN; p += 64) {
-          u64 ns = bits64 (s_start, p);
+        int e = -1;                                   // run end: first run start after s
+        for (int p = s + 1; p < G::WIN; p += 64) {
+          u64 ns = bits64 (T.start, p);
           if (ns) { e = p + __ffsll ((long long) ns) - 2; break; }
         }
-        const bool inval = (s_inval[s >> 5] >> (s & 31)) & 1u;
+        const bool inval = (T.inval[s >> 5] >> (s & 31)) & 1u;
         bool ok;
         long len;
         u64 left = 0, right = 0;
         u32 cb = 0, linv = 0, rinv = 0;
-        if (e >= 0 && e + k < TJ_WIN) {             // everything needed is in LDS
+        if (e >= 0 && e + k < G::WIN) {               // everything needed is in LDS
           len = e - s + 1;
-          ok = ((bits64 (s_sent, s - k) & kbits) == 0ull) && ((bits64 (s_sent, e + 1) & kbits) == 0ull);
+          ok = ((bits64 (T.sent, s - k) & kbits) == 0ull) && ((bits64 (T.sent, e + 1) & kbits) == 0ull);
           if (ok && !inval) {
-            left = bits64 (s_code, 2 * (s - k)) & km;
-            right = bits64 (s_code, 2 * (e + 1)) & km;
-            cb = (s_code[s >> 4] >> (2 * (s & 15))) & 3u;
-            if (cb >= 2u) { linv = (u32) (bits64 (s_inval, s - k) & kbits); rinv = (u32) (bits64 (s_inval, e + 1) & kbits); }
+            left = bits64 (T.code, 2 * (s - k)) & km;
+            right = bits64 (T.code, 2 * (e + 1)) & km;
+            cb = (T.code[s >> 4] >> (2 * (s & 15))) & 3u;
+            if (cb >= 2u) { linv = (u32) (bits64 (T.inval, s - k) & kbits); rinv = (u32) (bits64 (T.inval, e + 1) & kbits); }
           }
         }
-        else {                                      // tract runs past the window: walk the stream (rare)
+        else {                                        // tract runs past the window: walk the stream (rare)
           const u32 b = stream_byte (seq, n_bytes, gs);
           long ge = gs;
           while (stream_byte (seq, n_bytes, ge + 1) == b) ge++;
@@ -325,59 +357,496 @@ void scan_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, i
         }
         if (ok) {
           if (!inval) {
-            u32 base, flag;
             canonicalise (left, right, linv, rinv, cb, k, c0, c1, base, flag);
-            meta = make_meta (base, len, flag);
+            len10 = (u32) ((u64) len & 0x3FFull);     // 10-bit store of the reference (src/hopo_counter.h:39)
             pos = (u64) gs;
             have = true;
           }
-          else {                                    // non-ACGTU run: context comes from the previous tract of the read
+          else {                                      // non-ACGTU run: context comes from the previous tract of the read
             u64 at = atomicAdd (&ctr->n_fix, 1ull);
             if (at < fix_cap) { fix[at].pos = gs; fix[at].len = len; }
             else ctr->fix_overflow = 1u;
           }
         }
       }
-      emit_record<W> (have, c0, c1, meta, pos, out, cap, ctr);
+      sink.put (have, c0, c1, base, len10, flag, pos);
     }
     __syncthreads ();
   }
 }
 
 // Non-ACGTU runs that qualify as tracts (reference: src/hopo_counter.c:246-248: add_kmer is called with whatever the
-// previous tract of the same read left in context[], hopo_base_int and reverse_forward_flag).  One thread per entry
-// walks back through its read to the nearest earlier recorded tract of a valid base and re-uses its context.
-template <int W>
-__global__ void nrun_fixup_kernel (const uint8_t *__restrict__ seq, long n_bytes, int k, int mprime,
-                                   u64 *__restrict__ out, u64 cap, DevCounters *ctr, const FixEntry *fix, u32 fix_cap)
+// previous tract of the same read left in context[], hopo_base_int and reverse_forward_flag).  Walks back through the
+// read to the nearest earlier recorded tract of a valid base; false = there is none (undefined in the reference).
+__device__ bool stale_context (const uint8_t *__restrict__ seq, long n_bytes, long gs, int k, int mprime,
+                               u64 &c0, u64 &c1, u32 &base, u32 &flag)
+{
+  long p = gs - 1;
+  while (p >= 0 && seq[p] != '\n') {
+    const u32 b = seq[p];
+    long q = p;
+    while (q - 1 >= 0 && seq[q - 1] == b) q--;          // run [q, p]
+    if (byte_is_acgtu (b) && (p - q + 1) >= mprime) {
+      u64 left, right; u32 linv, rinv;
+      // recorded iff k bases of the same read precede it (its right side is fine: it ends before our run does);
+      // an earlier run would start even closer to the read start, so the search stops here either way
+      if (!flanks_from_stream (seq, n_bytes, q, p, k, left, right, linv, rinv)) return false;
+      canonicalise (left, right, linv, rinv, byte_code (b), k, c0, c1, base, flag);
+      return true;
+    }
+    p = q - 1;
+  }
+  return false;
+}
+
+// ---- sink 1: one list of located records (CPU-entry and test aid; small inputs) ------------------------------------
+
+struct ListSink
+{
+  u64 *out; u64 cap; DevCounters *ctr;
+  __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos)
+  {
+    emit_record<4> (have, c0, c1, make_meta (base, len10, flag), pos, out, cap, ctr);
+  }
+};
+
+__global__ __launch_bounds__ (256)
+void scan_list_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
+                       u64 *__restrict__ out, u64 cap, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
+{
+  __shared__ TileLds<256, 4096> T;
+  ListSink sink = {out, cap, ctr};
+  scan_tiles<256, 4096> (seq, n_bytes, n_tiles, k, mprime, T, sink, ctr, fix, fix_cap);
+}
+
+__global__ void nrun_fixup_list_kernel (const uint8_t *__restrict__ seq, long n_bytes, int k, int mprime,
+                                        u64 *__restrict__ out, u64 cap, DevCounters *ctr, const FixEntry *fix, u32 fix_cap)
 {
   u64 n_fix = ctr->n_fix;
   if (n_fix > fix_cap) n_fix = fix_cap;
   for (u64 i = blockIdx.x * (u64) blockDim.x + threadIdx.x; i < n_fix; i += (u64) gridDim.x * blockDim.x) {
-    const long gs = fix[i].pos;
-    bool found = false;
-    u64 left = 0, right = 0;
-    u32 cb = 0, linv = 0, rinv = 0;
-    long p = gs - 1;
-    while (p >= 0 && seq[p] != '\n') {
-      const u32 b = seq[p];
-      long q = p;
-      while (q - 1 >= 0 && seq[q - 1] == b) q--;       // run [q, p]
-      if (byte_is_acgtu (b) && (p - q + 1) >= mprime) {
-        // recorded iff k bases of the same read precede it (its right side is fine: it ends before our run does)
-        if (flanks_from_stream (seq, n_bytes, q, p, k, left, right, linv, rinv)) { found = true; cb = byte_code (b); }
-        break;                                          // an earlier run would start even closer to the read start
-      }
-      p = q - 1;
-    }
-    if (found) {
-      u64 c0, c1; u32 base, flag;
-      canonicalise (left, right, linv, rinv, cb, k, c0, c1, base, flag);
+    u64 c0, c1; u32 base, flag;
+    if (stale_context (seq, n_bytes, fix[i].pos, k, mprime, c0, c1, base, flag)) {
       u64 idx = atomicAdd (&ctr->n_rec, 1ull);
-      if (idx < cap) store_record<W> (out, idx, c0, c1, make_meta (base, fix[i].len, flag), (u64) gs);
+      if (idx < cap) store_record<4> (out, idx, c0, c1, make_meta (base, fix[i].len, flag), (u64) fix[i].pos);
       else ctr->overflow = 1u;
     }
     else atomicAdd (&ctr->n_undefined, 1ull);
+  }
+}
+
+// ---- compact raw records and their hash ---------------------------------------------------------------------------
+// Between the scan and the aggregation a raw tract is W 64-bit words, W chosen from k so that nothing is wasted:
+//   W = 1 (k <= 12): flag | len << 2 | ctx1 << 12 | ctx0 << (12 + 2k) | base << (12 + 4k)          (<= 61 bits)
+//   W = 2 (k <= 28): { ctx0 | len[7:0] << 56 ,  ctx1 | (len[9:8] | flag << 2 | base << 4) << 56 }
+//   W = 3          : { ctx0, ctx1, base | len << 2 | flag << 12 }
+
+template <int W> __device__ __forceinline__ void pack_raw (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w);
+template <> __device__ __forceinline__ void pack_raw<1> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
+{ w[0] = (u64) flag | ((u64) len10 << 2) | (c1 << 12) | (c0 << (12 + 2 * k)) | ((u64) base << (12 + 4 * k)); }
+template <> __device__ __forceinline__ void pack_raw<2> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
+{ w[0] = c0 | ((u64) (len10 & 0xFFu) << 56); w[1] = c1 | ((u64) ((len10 >> 8) | (flag << 2) | (base << 4)) << 56); }
+template <> __device__ __forceinline__ void pack_raw<3> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
+{ w[0] = c0; w[1] = c1; w[2] = (u64) base | ((u64) len10 << 2) | ((u64) flag << 12); }
+
+template <int W> __device__ __forceinline__ void unpack_raw (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag);
+template <> __device__ __forceinline__ void unpack_raw<1> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
+{
+  const u64 x = w[0], km = kmask (k);
+  flag = (u32) (x & 3ull); len10 = (u32) ((x >> 2) & 0x3FFull); c1 = (x >> 12) & km; c0 = (x >> (12 + 2 * k)) & km; base = (u32) ((x >> (12 + 4 * k)) & 1ull);
+}
+template <> __device__ __forceinline__ void unpack_raw<2> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
+{
+  const u64 m56 = (1ull << 56) - 1ull;
+  const u32 hi = (u32) (w[1] >> 56);
+  c0 = w[0] & m56; c1 = w[1] & m56; len10 = (u32) (w[0] >> 56) | ((hi & 3u) << 8); flag = (hi >> 2) & 3u; base = (hi >> 4) & 1u;
+}
+template <> __device__ __forceinline__ void unpack_raw<3> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
+{ c0 = w[0]; c1 = w[1]; base = (u32) (w[2] & 3ull); len10 = (u32) ((w[2] >> 2) & 0x3FFull); flag = (u32) ((w[2] >> 12) & 3ull); }
+
+// hash of the reduction key (base, context, stored length): bits 0-8 pick the bucket, 9-20 the table slot, 32-63 the tag
+__device__ __forceinline__ u64 hash_key (u64 c0, u64 c1, u32 base, u32 len10)
+{
+  u64 h = (c0 + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+  h ^= (c1 + 0xD6E8FEB86659FD93ull) * 0x94D049BB133111EBull;
+  h ^= ((u64) (base | (len10 << 2)) + 1ull) * 0xD1B54A32D192ED03ull;
+  h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+  return h;
+}
+
+#define TJ_P        512                 // hash buckets
+#define TJ_BINWORDS 24                  // 64-bit words per LDS write-combining bin (192 bytes)
+#define TJ_CH0      1536                // chunk size unit in records (multiple of every bin's record count 24 / 12 / 8)
+#define TJ_EMPTY    0xFFFFFFFFu
+
+// Bucket storage.  A bucket is a sequence of records numbered by its cursor; record `pos` lives in the bucket's
+// (pos / CH)-th chunk.  Chunks come from one pool and are claimed on first touch by a compare-and-swap on the
+// bucket's chunk table (a lost race only leaks the loser's chunk), so a skewed hash distribution costs nothing:
+// memory follows the data, not the worst bucket.
+struct Buckets
+{
+  u64 *pool;          // pool_chunks * CH * W words
+  u32 *table;         // [TJ_P][maxj] chunk ids, TJ_EMPTY = not claimed yet
+  u32 *cursors;       // [TJ_P] records reserved per bucket
+  u32 *pool_next;     // next free chunk
+  u32 pool_chunks, maxj, ch_shift;      // CH = TJ_CH0 << ch_shift
+};
+
+#define TJ_NOCHUNK  0xFFFFFFFEu         // published instead of a chunk id when the pool is exhausted
+#define TJ_SPIN_MAX (1u << 20)
+
+__device__ __forceinline__ u32 chunk_of_pos (const Buckets &B, u32 pos) { return (pos / TJ_CH0) >> B.ch_shift; }
+
+// The reservation [p0, p0 + n) of bucket b (n <= 24): if it holds the FIRST record of a chunk, take a chunk from the
+// pool and publish it in the bucket's table.  Exactly one reservation holds that record, so exactly one thread claims
+// each chunk; everybody else waits for the entry in bucket_slot().  Call it right after reserving, before any wait.
+__device__ __forceinline__ void bucket_claim (const Buckets &B, u32 b, u32 p0, u32 n, DevCounters *ctr)
+{
+  const u32 j = chunk_of_pos (B, p0 + n - 1);
+  const u32 first = (j * TJ_CH0) << B.ch_shift;
+  if (first < p0) return;                               // the chunk was started by an earlier reservation
+  if (j >= B.maxj) { ctr->overflow = 1u; return; }
+  const u32 mine = atomicAdd (B.pool_next, 1u);
+  if (mine >= B.pool_chunks) ctr->overflow = 1u;
+  __hip_atomic_store (B.table + (u64) b * B.maxj + j, mine < B.pool_chunks ? mine : TJ_NOCHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// index (in records) inside the pool of record `pos` of bucket b; ~0 if it has no storage.  wait = the chunk may still
+// be in the hands of the thread that claims it (same launch): poll the table entry, bounded.
+__device__ __forceinline__ u64 bucket_slot (const Buckets &B, u32 b, u32 pos, bool wait, DevCounters *ctr)
+{
+  const u32 j = chunk_of_pos (B, pos);
+  const u32 off = pos - ((j * TJ_CH0) << B.ch_shift);
+  if (j >= B.maxj) return ~0ull;
+  u32 *e = B.table + (u64) b * B.maxj + j;
+  u32 ch = __hip_atomic_load (e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (wait) {
+    for (u32 spins = 0; ch == TJ_EMPTY && spins < TJ_SPIN_MAX; spins++) {
+      __builtin_amdgcn_s_sleep (4);
+      ch = __hip_atomic_load (e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (ch == TJ_EMPTY && ctr) ctr->overflow = 1u;
+  }
+  if (ch >= TJ_NOCHUNK) return ~0ull;
+  return (((u64) ch * TJ_CH0) << B.ch_shift) + off;
+}
+
+template <int W>
+__device__ __forceinline__ void bucket_insert_slow (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, const Buckets &B, DevCounters *ctr)
+{
+  u64 w[W];
+  pack_raw<W> (c0, c1, base, len10, flag, k, w);
+  const u32 b = (u32) hash_key (c0, c1, base, len10) & (TJ_P - 1);
+  const u32 pos = atomicAdd (&B.cursors[b], 1u);
+  bucket_claim (B, b, pos, 1u, ctr);
+  const u64 at = bucket_slot (B, b, pos, true, ctr);
+  if (at != ~0ull) { u64 *q = B.pool + at * W; for (int j = 0; j < W; j++) q[j] = w[j]; }
+}
+
+// ---- sink 2: hash-partition into TJ_P buckets through LDS write-combining bins --------------------------------------
+
+template <int W>
+struct BinLds
+{
+  u64 bins[TJ_P * TJ_BINWORDS];
+  u64 gpos[TJ_P];
+  u32 cnt[TJ_P];
+  u32 list[TJ_P];
+  u32 p0[TJ_P];
+  u32 nfull;
+};
+
+template <int W, int BLOCK>
+struct BinSink
+{
+  static constexpr int C = TJ_BINWORDS / W;             // records per bin: 24, 12, 8
+  BinLds<W> &L;
+  Buckets B; DevCounters *ctr; int k;
+
+  __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos)
+  {
+    const int tid = threadIdx.x;
+    u64 w[W];
+    u32 b = 0;
+    if (have) { pack_raw<W> (c0, c1, base, len10, flag, k, w); b = (u32) hash_key (c0, c1, base, len10) & (TJ_P - 1); }
+    bool pending = have;
+    for (;;) {
+      if (pending) {
+        const u32 s = atomicAdd (&L.cnt[b], 1u);
+        if (s < (u32) C) {
+          u64 *q = L.bins + (b * C + s) * W;
+#pragma unroll
+          for (int j = 0; j < W; j++) q[j] = w[j];
+          pending = false;
+        }
+      }
+      const int anyp = __syncthreads_or (pending ? 1 : 0);
+      const bool full = (tid < TJ_P) && (L.cnt[tid] >= (u32) C);
+      const int nfull = __syncthreads_count (full ? 1 : 0);
+      if (nfull) {                                      // write every full bin as one 192-byte piece of its bucket
+        if (full) {
+          const u32 at = atomicAdd (&L.nfull, 1u);
+          L.list[at] = (u32) tid;
+          const u32 p0 = atomicAdd (&B.cursors[tid], (u32) C);
+          bucket_claim (B, (u32) tid, p0, (u32) C, ctr);
+          L.p0[tid] = p0;
+          L.cnt[tid] = 0;
+        }
+        __syncthreads ();                               // every claim of this workgroup is out before anybody waits
+        if (full) {
+          const u32 p0 = L.p0[tid];
+          if (chunk_of_pos (B, p0) == chunk_of_pos (B, p0 + C - 1)) L.gpos[tid] = bucket_slot (B, (u32) tid, p0, true, ctr);
+          else {                                        // the piece straddles two chunks (rare): record by record
+            L.gpos[tid] = ~0ull;
+            for (int r = 0; r < C; r++) {
+              const u64 g = bucket_slot (B, (u32) tid, p0 + r, true, ctr);
+              if (g != ~0ull) for (int j = 0; j < W; j++) B.pool[g * W + j] = L.bins[tid * TJ_BINWORDS + r * W + j];
+            }
+          }
+        }
+        __syncthreads ();
+        for (int i = tid; i < nfull * TJ_BINWORDS; i += BLOCK) {
+          const u32 bin = L.list[i / TJ_BINWORDS];
+          const int wj = i % TJ_BINWORDS;
+          const u64 g = L.gpos[bin];
+          if (g != ~0ull) B.pool[g * W + wj] = L.bins[bin * TJ_BINWORDS + wj];
+        }
+        __syncthreads ();
+        if (tid == 0) L.nfull = 0;
+      }
+      if (!anyp) break;
+    }
+  }
+
+  __device__ __forceinline__ void finish ()
+  { // partial bins at the end of the workgroup's life
+    const int tid = threadIdx.x;
+    __syncthreads ();
+    if (tid < TJ_P) {
+      const u32 n = min (L.cnt[tid], (u32) C);
+      if (n) {                                          // record by record: the tail may cross into a new chunk
+        const u32 p0 = atomicAdd (&B.cursors[tid], n);
+        bucket_claim (B, (u32) tid, p0, n, ctr);
+        for (u32 r = 0; r < n; r++) {
+          const u64 g = bucket_slot (B, (u32) tid, p0 + r, true, ctr);
+          if (g != ~0ull) for (int j = 0; j < W; j++) B.pool[g * W + j] = L.bins[tid * TJ_BINWORDS + r * W + j];
+        }
+      }
+    }
+  }
+};
+
+#define TJ_SB_BLOCK 1024
+#define TJ_SB_TILE  16384
+
+template <int W>
+__global__ __launch_bounds__ (TJ_SB_BLOCK)
+void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
+                       Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
+{
+  __shared__ TileLds<TJ_SB_BLOCK, TJ_SB_TILE> T;
+  __shared__ BinLds<W> B;
+  for (int i = threadIdx.x; i < TJ_P; i += TJ_SB_BLOCK) B.cnt[i] = 0;
+  if (threadIdx.x == 0) B.nfull = 0;
+  __syncthreads ();
+  BinSink<W, TJ_SB_BLOCK> sink = {B, BK, ctr, k};
+  scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE> (seq, n_bytes, n_tiles, k, mprime, T, sink, ctr, fix, fix_cap);
+  sink.finish ();
+}
+
+template <int W>
+__global__ void nrun_fixup_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, int k, int mprime,
+                                        Buckets BK, DevCounters *ctr, const FixEntry *fix, u32 fix_cap)
+{
+  u64 n_fix = ctr->n_fix;
+  if (n_fix > fix_cap) n_fix = fix_cap;
+  for (u64 i = blockIdx.x * (u64) blockDim.x + threadIdx.x; i < n_fix; i += (u64) gridDim.x * blockDim.x) {
+    u64 c0, c1; u32 base, flag;
+    if (stale_context (seq, n_bytes, fix[i].pos, k, mprime, c0, c1, base, flag))
+      bucket_insert_slow<W> (c0, c1, base, (u32) ((u64) fix[i].len & 0x3FFull), flag, k, BK, ctr);
+    else atomicAdd (&ctr->n_undefined, 1ull);
+  }
+}
+
+// host hopo_element array (40 B each) -> buckets
+template <int W>
+__global__ void bin_elems_kernel (const u64 *__restrict__ elems5, long n, int k, Buckets BK, DevCounters *ctr)
+{
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
+    const u64 m = elems5[5 * i + 2];
+    bucket_insert_slow<W> (elems5[5 * i], elems5[5 * i + 1], (u32) (m & 3ull), (u32) ((m >> TJ_META_LEN_SHIFT) & 0x3FFull),
+                           (u32) ((m >> TJ_META_FLAG_SHIFT) & 3ull), k, BK, ctr);
+  }
+}
+
+// buckets -> flat list of 24-byte raw records (test aid)
+template <int W>
+__global__ void unpack_buckets_kernel (Buckets BK, const u64 *__restrict__ prefix, int k, u64 *__restrict__ out)
+{
+  const u32 b = blockIdx.x;
+  const u32 n = BK.cursors[b];
+  for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+    u64 c0, c1; u32 base, len10, flag;
+    const u64 at = bucket_slot (BK, b, i, false, nullptr);
+    if (at == ~0ull) continue;
+    unpack_raw<W> (BK.pool + at * W, k, c0, c1, base, len10, flag);
+    u64 *q = out + 3 * (prefix[b] + i);
+    q[0] = c0; q[1] = c1; q[2] = make_meta (base, len10, flag);
+  }
+}
+
+// chunk table with a longer row
+__global__ void table_relayout_kernel (const u32 *__restrict__ old, u32 old_maxj, u32 *__restrict__ neu, u32 new_maxj)
+{
+  const u32 b = blockIdx.x;
+  for (u32 j = threadIdx.x; j < old_maxj; j += blockDim.x) neu[(u64) b * new_maxj + j] = old[(u64) b * old_maxj + j];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// aggregation: one workgroup per bucket streams its raw records through an LDS hash table keyed by
+// (base, context, stored length), counting the two strands separately (reference: the qsort + run-length pass of
+// src/hopo_counter.c:351-365), then applies the strand / singleton filter (:367-374) and appends the survivors, as
+// 24-byte records carrying count and canon_flag, to the kept list.  A table that fills up closes (no new keys, absent
+// keys go back to the front of the bucket) and the leftovers are aggregated in further rounds; a key is always
+// entirely in one round, so rounds never split a count.
+
+#define AG_S        4096                // table slots
+#define AG_CLOSE_AT 2048                // stop admitting new keys beyond this many (one batch may add 1024 more)
+#define AG_BLOCK    1024
+
+struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow; };
+
+struct AggLds
+{
+  u64 k0[AG_S];
+  u64 k1[AG_S];
+  u32 tag[AG_S];                        // 0 empty; (hash[63:34] << 2) | 1 published; | 2 while its key is being written
+  u32 k2[AG_S];                         // base | stored length << 2
+  u32 cf[AG_S];                         // occurrences as read (canon_flag 1)
+  u32 cr[AG_S];                         // occurrences reverse-complemented (canon_flag 2)
+  u32 n_claimed, n_ovf, closed, total;
+  u32 wsum[AG_BLOCK / 64];
+};
+
+__device__ __forceinline__ bool agg_insert (AggLds &L, u64 c0, u64 c1, u32 k2, u32 flag, u64 h, bool closed)
+{ // true = counted; false = key absent from a closed table
+  const u32 mytag = ((u32) (h >> 32) & ~3u) | 1u;
+  u32 slot = (u32) (h >> 9) & (AG_S - 1);
+  for (u32 probes = 0; probes < AG_S;) {
+    u32 t;
+    if (!closed) {
+      u32 expected = 0u;
+      __hip_atomic_compare_exchange_strong (&L.tag[slot], &expected, mytag | 2u, __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      t = expected;                                     // previous value (0 = we own the slot now)
+    }
+    else t = __hip_atomic_load (&L.tag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (t == 0u) {
+      if (closed) return false;
+      L.k0[slot] = c0; L.k1[slot] = c1; L.k2[slot] = k2;
+      atomicAdd (&L.n_claimed, 1u);
+      __hip_atomic_store (&L.tag[slot], mytag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // publish
+      atomicAdd ((flag & 2u) ? &L.cr[slot] : &L.cf[slot], 1u);
+      return true;
+    }
+    if (t == (mytag | 2u)) continue;                    // same tag, key still being written by its owner: look again
+    if (t == mytag && L.k0[slot] == c0 && L.k1[slot] == c1 && L.k2[slot] == k2) {
+      atomicAdd ((flag & 2u) ? &L.cr[slot] : &L.cf[slot], 1u);
+      return true;
+    }
+    slot = (slot + 1u) & (AG_S - 1);
+    probes++;
+  }
+  return false;
+}
+
+template <int W>
+__global__ __launch_bounds__ (AG_BLOCK)
+void aggregate_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+{
+  __shared__ AggLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 bkt = blockIdx.x;
+  u32 n = BK.cursors[bkt];
+
+  while (n > 0) {
+    for (int i = tid; i < AG_S; i += AG_BLOCK) { L.tag[i] = 0; L.cf[i] = 0; L.cr[i] = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.closed = 0; }
+    __syncthreads ();
+
+    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK) {
+      const u32 idx = b0 + tid;
+      const bool have = idx < n;
+      u64 w[W];
+      bool valid = false;
+      if (have) {
+        const u64 at = bucket_slot (BK, bkt, idx, false, nullptr);
+        valid = at != ~0ull;                            // (a record that could not be placed was already reported)
+        if (valid) {
+#pragma unroll
+          for (int j = 0; j < W; j++) w[j] = BK.pool[at * W + j];
+        }
+      }
+      if (tid == 0) L.closed = (L.n_claimed > AG_CLOSE_AT) ? 1u : 0u;
+      __syncthreads ();                                 // batch is in registers; table state decided for the batch
+      const bool closed = L.closed != 0u;
+      if (valid) {
+        u64 c0, c1; u32 base, len10, flag;
+        unpack_raw<W> (w, k, c0, c1, base, len10, flag);
+        if (!agg_insert (L, c0, c1, base | (len10 << 2), flag, hash_key (c0, c1, base, len10), closed)) {
+          const u32 o = atomicAdd (&L.n_ovf, 1u);        // o <= records read so far: never ahead of the reads
+          const u64 at = bucket_slot (BK, bkt, o, false, nullptr);
+          if (at != ~0ull) {
+#pragma unroll
+            for (int j = 0; j < W; j++) BK.pool[at * W + j] = w[j];
+          }
+        }
+      }
+      __syncthreads ();                                 // n_claimed is exact before the next decision
+    }
+
+    // emit this round's keys: filter, then one global atomic per workgroup
+    u32 mine = 0;
+    u64 metas[AG_S / AG_BLOCK];
+#pragma unroll
+    for (int r = 0; r < AG_S / AG_BLOCK; r++) {
+      const int slot = tid + r * AG_BLOCK;
+      metas[r] = 0;
+      if (L.tag[slot]) {
+        const u32 cf = L.cf[slot], cr = L.cr[slot];
+        const u64 flag = (cf ? 1ull : 0ull) | (cr ? 2ull : 0ull);
+        const u64 cnt = ((u64) cf + (u64) cr) & 0xFFFFFull;           // 20-bit store wraps (reference :361)
+        const int scnt = (cnt & 0x80000ull) ? (int) cnt - 0x100000 : (int) cnt;
+        const bool keep = remove_biased ? (flag == 3ull) : (scnt > 1);
+        if (keep) {
+          const u32 k2 = L.k2[slot];
+          metas[r] = (u64) (k2 & 3u) | ((u64) (k2 >> 2) << TJ_META_LEN_SHIFT) | (cnt << TJ_META_COUNT_SHIFT) |
+                     (0xffeull << TJ_META_MISM_SHIFT) | (flag << TJ_META_FLAG_SHIFT) | (1ull << 63);   // bit 63: marker, cleared on store
+          mine++;
+        }
+      }
+    }
+    u32 x = mine;                                       // exclusive scan over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up (x, o); if (lane >= o) x += y; }
+    if (lane == 63) L.wsum[wave] = x;
+    __syncthreads ();
+    u32 wbase = 0, total = 0;
+    for (int wv = 0; wv < AG_BLOCK / 64; wv++) { const u32 s = L.wsum[wv]; if (wv < wave) wbase += s; total += s; }
+    if (tid == 0) L.total = total ? atomicAdd (&fin->n_kept, total) : 0u;
+    __syncthreads ();
+    u64 at = (u64) L.total + wbase + x - mine;
+#pragma unroll
+    for (int r = 0; r < AG_S / AG_BLOCK; r++)
+      if (metas[r]) {
+        const int slot = tid + r * AG_BLOCK;
+        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = L.k0[slot]; q[1] = L.k1[slot]; q[2] = metas[r] & ~(1ull << 63); }
+        else fin->overflow = 1u;
+        at++;
+      }
+    __threadfence_block ();
+    __syncthreads ();
+    n = L.n_ovf;                                        // leftovers now sit at the front of the bucket
+    __syncthreads ();
   }
 }
 
@@ -531,8 +1000,6 @@ void scan_apply_kernel (const u32 *__restrict__ in, u32 *__restrict__ out, long 
 // ---------------------------------------------------------------------------------------------------------------
 // reduce runs of equal keys (reference: src/hopo_counter.c:356-374), context index (:388-404), coverage (:419-438)
 
-struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 pad; };
-
 __device__ __forceinline__ bool same_key (const u64 *a, const u64 *b)
 { // base, context, length (not the flag, not the count)
   const u64 km = (3ull << TJ_META_BASE_SHIFT) | (0x3FFull << TJ_META_LEN_SHIFT);
@@ -563,36 +1030,6 @@ __global__ void seg_headpos_kernel (const u32 *__restrict__ flags, const u32 *__
 {
   for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x)
     if (flags[i]) headpos[segid[i]] = (u32) i;
-}
-
-// one thread per run of equal keys: multiplicity, OR of strand flags, filter decision
-__global__ void seg_decide_kernel (const u64 *__restrict__ rec, long n, const u32 *__restrict__ headpos, const u32 *n_seg_p,
-                                   int remove_biased, u32 *__restrict__ keep, u64 *__restrict__ seg_meta)
-{
-  const u32 n_seg = *n_seg_p;
-  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n_seg; j += gridDim.x * blockDim.x) {
-    const long s = headpos[j], e = (j + 1 < n_seg) ? (long) headpos[j + 1] : n;
-    const u64 mf = rec[3 * s + 2], ml = rec[3 * (e - 1) + 2];
-    const u64 flag = ((mf | ml) >> TJ_META_FLAG_SHIFT) & 3ull;          // sorted by flag inside the run
-    const u64 cnt = (u64) (e - s) & 0xFFFFFull;                          // 20-bit store wraps (reference :361)
-    u64 meta = mf & ~((0xFFFFFull << TJ_META_COUNT_SHIFT) | (7ull << TJ_META_FLAG_SHIFT));
-    meta |= (cnt << TJ_META_COUNT_SHIFT) | (flag << TJ_META_FLAG_SHIFT);
-    seg_meta[j] = meta;
-    keep[j] = remove_biased ? (flag == 3ull) : (meta_count (meta) > 1);
-  }
-}
-
-__global__ void seg_write_kernel (const u64 *__restrict__ rec, const u32 *__restrict__ headpos, const u32 *n_seg_p,
-                                  const u32 *__restrict__ keep, const u32 *__restrict__ outpos, const u64 *__restrict__ seg_meta,
-                                  u64 *__restrict__ kept)
-{
-  const u32 n_seg = *n_seg_p;
-  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n_seg; j += gridDim.x * blockDim.x)
-    if (keep[j]) {
-      const long s = headpos[j];
-      u64 *q = kept + 3 * (u64) outpos[j];
-      q[0] = rec[3 * s]; q[1] = rec[3 * s + 1]; q[2] = seg_meta[j];
-    }
 }
 
 // one thread per context of the kept array: depth, index decision
@@ -647,13 +1084,6 @@ __global__ void cov_max_kernel (const u32 *__restrict__ keys, const int *__restr
 
 __global__ void set_int_kernel (int *p, int v) { *p = v; }
 
-// hopo_element (40 B, host layout) -> 24 B device record
-__global__ void elem_to_record_kernel (const u64 *__restrict__ elems5, long n, u64 *__restrict__ rec)
-{
-  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
-    rec[3 * i] = elems5[5 * i]; rec[3 * i + 1] = elems5[5 * i + 1]; rec[3 * i + 2] = elems5[5 * i + 2];
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side of the thin layer
@@ -666,15 +1096,20 @@ struct DevBuf
 
 struct tjamd_counter
 {
-  int device = 0, k = 0;
+  int device = 0, k = 0, W = 3, n_cu = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
-  DevCounters *d_ctr = nullptr, *h_ctr = nullptr;     // raw list counters (device / pinned host mirror)
-  DevCounters *d_lctr = nullptr;                      // located list counters
-  DevBuf raw, alt, stage, fix, loc;
+  DevCounters *d_ctr = nullptr, *h_ctr = nullptr;     // scan counters (device / pinned host mirror)
+  DevCounters *d_lctr = nullptr;                      // located-list counters
+  u32 *d_cursors = nullptr, *h_cursors = nullptr;     // [TJ_P] records per bucket, then [TJ_P] = next free chunk
+  DevBuf pool, table, stage, fix, loc, prefix, rawlist;
+  u32 pool_chunks = 0, maxj = 0;
+  int ch_shift = -1;          // chunk = TJ_CH0 << ch_shift records; fixed by the first scan after a reset
+  u64 bucket_bound = 0;       // upper bound of the fullest bucket (exact after a synchronisation)
+  u64 chunk_bound = 0;        // upper bound of the chunks handed out
   long n_raw_known = 0;       // exact after the last synchronisation
-  long n_raw_bound = 0;       // known + worst case of the scans launched since
   long n_undefined = 0;
-  DevBuf hist, flags, segid, headpos, keep, outpos, segmeta, scan_tmp, kept, idx_i, idx_f, cov_keys, cov_sums;
+  double slack = 1.0;
+  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov_keys, cov_sums;
   FinCounts *d_fin = nullptr, *h_fin = nullptr;
   long n_kept = 0; int n_idx = 0, coverage = 0, status = -1;
   hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_f0 = nullptr, ev_f1 = nullptr;
@@ -710,15 +1145,24 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   HIPCHK_NULL (hipSetDevice (device));
   tjamd_counter *c = new tjamd_counter ();
   c->device = device; c->k = kmer_size;
+  c->W = (kmer_size <= 12) ? 1 : (kmer_size <= 28) ? 2 : 3;
+  hipDeviceProp_t prop;
+  HIPCHK_NULL (hipGetDeviceProperties (&prop, device));
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const char *sl = getenv ("TATAJUBA_AMD_BUCKET_SLACK");
+  if (sl && atof (sl) >= 1.0) c->slack = atof (sl);
   HIPCHK_NULL (hipStreamCreateWithFlags (&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIPCHK_NULL (hipMalloc ((void **) &c->d_ctr, sizeof (DevCounters)));
   HIPCHK_NULL (hipMalloc ((void **) &c->d_lctr, sizeof (DevCounters)));
   HIPCHK_NULL (hipMalloc ((void **) &c->d_fin, sizeof (FinCounts)));
+  HIPCHK_NULL (hipMalloc ((void **) &c->d_cursors, (TJ_P + 1) * sizeof (u32)));
   HIPCHK_NULL (hipHostMalloc ((void **) &c->h_ctr, sizeof (DevCounters), hipHostMallocDefault));
   HIPCHK_NULL (hipHostMalloc ((void **) &c->h_fin, sizeof (FinCounts), hipHostMallocDefault));
+  HIPCHK_NULL (hipHostMalloc ((void **) &c->h_cursors, (TJ_P + 1) * sizeof (u32), hipHostMallocDefault));
   HIPCHK_NULL (hipMemsetAsync (c->d_ctr, 0, sizeof (DevCounters), c->stream));
   HIPCHK_NULL (hipMemsetAsync (c->d_lctr, 0, sizeof (DevCounters), c->stream));
+  HIPCHK_NULL (hipMemsetAsync (c->d_cursors, 0, (TJ_P + 1) * sizeof (u32), c->stream));
   HIPCHK_NULL (hipEventCreate (&c->ev_s0)); HIPCHK_NULL (hipEventCreate (&c->ev_s1));
   HIPCHK_NULL (hipEventCreate (&c->ev_f0)); HIPCHK_NULL (hipEventCreate (&c->ev_f1));
   HIPCHK_NULL (hipStreamSynchronize (c->stream));
@@ -730,14 +1174,16 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   if (!c) return;
   (void) hipSetDevice (c->device);
   (void) hipStreamSynchronize (c->stream);
-  DevBuf *all[] = {&c->raw, &c->alt, &c->stage, &c->fix, &c->loc, &c->hist, &c->flags, &c->segid, &c->headpos, &c->keep, &c->outpos,
-                   &c->segmeta, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov_keys, &c->cov_sums};
+  DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
+                   &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov_keys, &c->cov_sums};
   for (DevBuf *b : all) release (*b);
   if (c->d_ctr) (void) hipFree (c->d_ctr);
   if (c->d_lctr) (void) hipFree (c->d_lctr);
   if (c->d_fin) (void) hipFree (c->d_fin);
+  if (c->d_cursors) (void) hipFree (c->d_cursors);
   if (c->h_ctr) (void) hipHostFree (c->h_ctr);
   if (c->h_fin) (void) hipHostFree (c->h_fin);
+  if (c->h_cursors) (void) hipHostFree (c->h_cursors);
   if (c->ev_s0) (void) hipEventDestroy (c->ev_s0);
   if (c->ev_s1) (void) hipEventDestroy (c->ev_s1);
   if (c->ev_f0) (void) hipEventDestroy (c->ev_f0);
@@ -757,69 +1203,158 @@ extern "C" int tjamd_counter_set_stream (tjamd_counter *c, void *hip_stream)
   return TJAMD_OK;
 }
 
+static Buckets make_buckets (const tjamd_counter *c)
+{
+  Buckets B;
+  B.pool = (u64 *) c->pool.p; B.table = (u32 *) c->table.p; B.cursors = c->d_cursors; B.pool_next = c->d_cursors + TJ_P;
+  B.pool_chunks = c->pool_chunks; B.maxj = c->maxj; B.ch_shift = (u32) std::max (c->ch_shift, 0);
+  return B;
+}
+
+// forget every raw record: cursors and chunk counter to zero, chunk table to "unclaimed"
+static int clear_buckets (tjamd_counter *c)
+{
+  HIPCHK (hipMemsetAsync (c->d_cursors, 0, (TJ_P + 1) * sizeof (u32), c->stream));
+  if (c->table.p && c->maxj) HIPCHK (hipMemsetAsync (c->table.p, 0xFF, (size_t) TJ_P * c->maxj * 4, c->stream));
+  c->n_raw_known = 0; c->bucket_bound = 0; c->chunk_bound = 0; c->ch_shift = -1;
+  return TJAMD_OK;
+}
+
 extern "C" int tjamd_counter_reset (tjamd_counter *c)
 {
   if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
   HIPCHK (hipSetDevice (c->device));
   HIPCHK (hipMemsetAsync (c->d_ctr, 0, sizeof (DevCounters), c->stream));
-  c->n_raw_known = c->n_raw_bound = 0; c->n_undefined = 0;
+  int rc = clear_buckets (c);
+  if (rc) return rc;
+  c->n_undefined = 0;
   c->n_kept = 0; c->n_idx = 0; c->coverage = 0; c->status = -1;
   return TJAMD_OK;
 }
 
+extern "C" void *tjamd_host_alloc (size_t bytes)
+{
+  void *p = nullptr;
+  if (hipHostMalloc (&p, bytes, hipHostMallocDefault) != hipSuccess) { set_err (TJAMD_ERR_HIP, "hipHostMalloc of %zu bytes failed", bytes); return NULL; }
+  return p;
+}
+
+extern "C" void tjamd_host_free (void *p) { if (p) (void) hipHostFree (p); }
+
+extern "C" int tjamd_sync (tjamd_counter *c)
+{
+  if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
+  HIPCHK (hipSetDevice (c->device));
+  HIPCHK (hipStreamSynchronize (c->stream));
+  return TJAMD_OK;
+}
+
+// stream synchronisation + exact counts
 static int sync_counters (tjamd_counter *c)
 {
   HIPCHK (hipMemcpyAsync (c->h_ctr, c->d_ctr, sizeof (DevCounters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK (hipMemcpyAsync (c->h_cursors, c->d_cursors, (TJ_P + 1) * sizeof (u32), hipMemcpyDeviceToHost, c->stream));
   HIPCHK (hipStreamSynchronize (c->stream));
-  if (c->h_ctr->overflow) return set_err (TJAMD_ERR_CAPACITY, "raw record list overflowed (%llu records, capacity %zu)",
-                                         (unsigned long long) c->h_ctr->n_rec, c->raw.cap / 24);
+  long total = 0;
+  u64 mx = 0;
+  for (int b = 0; b < TJ_P; b++) { total += c->h_cursors[b]; mx = std::max<u64> (mx, c->h_cursors[b]); }
+  if (c->h_ctr->overflow)
+    return set_err (TJAMD_ERR_CAPACITY, "raw record storage exhausted (%u of %u chunks handed out, fullest bucket %llu records): "
+                    "raise TATAJUBA_AMD_BUCKET_SLACK (now %.1f) and scan again", c->h_cursors[TJ_P], c->pool_chunks, (unsigned long long) mx, c->slack);
   if (c->h_ctr->fix_overflow) return set_err (TJAMD_ERR_CAPACITY, "too many non-ACGTU tract candidates in one batch (%llu)",
                                              (unsigned long long) c->h_ctr->n_fix);
-  c->n_raw_known = c->n_raw_bound = (long) c->h_ctr->n_rec;
+  c->n_raw_known = total;
+  c->bucket_bound = mx;
+  c->chunk_bound = c->h_cursors[TJ_P];
   c->n_undefined = (long) c->h_ctr->n_undefined;
+  return TJAMD_OK;
+}
+
+// room for `add` more raw records (an upper bound), wherever the hash sends them
+static int ensure_buckets (tjamd_counter *c, u64 add)
+{
+  if (c->ch_shift < 0) {                                // chunk size: at most ~16 k chunks for this many records
+    const u64 units = add / (16384ull * TJ_CH0);
+    int sft = 0;
+    while ((1ull << sft) < units) sft++;
+    c->ch_shift = sft;
+  }
+  const u64 ch = (u64) TJ_CH0 << c->ch_shift;
+  // every bucket may open one more chunk than its records need; claims never leak (one claimer per chunk)
+  const u64 need_chunks = c->chunk_bound + (add + ch - 1) / ch + TJ_P;
+  const u64 need_maxj = (c->bucket_bound + add + ch - 1) / ch + 2;      // worst case: everything hashes to one bucket
+  if (need_chunks >= TJ_NOCHUNK || need_maxj >= (1ull << 31)) return set_err (TJAMD_ERR_CAPACITY, "batch too large for the chunk table");
+  int rc = ensure (c->pool, (size_t) need_chunks * ch * c->W * 8, c->stream, std::min<size_t> ((size_t) (c->chunk_bound * ch * c->W * 8), c->pool.cap));
+  if (rc) return rc;
+  c->pool_chunks = (u32) std::min<u64> (c->pool.cap / (ch * c->W * 8), TJ_NOCHUNK - 1);
+  if (need_maxj > c->maxj) {
+    const u32 nmaxj = (u32) std::max<u64> (need_maxj, (u64) c->maxj + c->maxj / 2);
+    void *np = nullptr;
+    hipError_t e = hipMalloc (&np, (size_t) TJ_P * nmaxj * 4);
+    if (e != hipSuccess) return set_err (TJAMD_ERR_HIP, "hipMalloc of the chunk table failed: %s", hipGetErrorString (e));
+    HIPCHK (hipMemsetAsync (np, 0xFF, (size_t) TJ_P * nmaxj * 4, c->stream));
+    if (c->table.p) {
+      if (c->maxj) {
+        hipLaunchKernelGGL (table_relayout_kernel, dim3 (TJ_P), dim3 (256), 0, c->stream, (const u32 *) c->table.p, c->maxj, (u32 *) np, nmaxj);
+        HIPCHK (hipGetLastError ());
+      }
+      HIPCHK (hipStreamSynchronize (c->stream));
+      HIPCHK (hipFree (c->table.p));
+    }
+    c->table.p = np; c->table.cap = (size_t) TJ_P * nmaxj * 4; c->maxj = nmaxj;
+  }
+  c->chunk_bound = need_chunks;
+  c->bucket_bound += add;
   return TJAMD_OK;
 }
 
 #define TJ_FIX_CAP (1u << 20)
 
-template <int W>
-static int launch_scan (tjamd_counter *c, const uint8_t *d_seq, size_t n_bytes, int mprime, u64 *out, u64 cap, DevCounters *ctr)
+static int check_scan_args (tjamd_counter *c, int min_tract_size)
 {
-  int rc = ensure (c->fix, (size_t) TJ_FIX_CAP * sizeof (FixEntry), c->stream);
-  if (rc) return rc;
-  long n_tiles = (long) ((n_bytes + TJ_TILE - 1) / TJ_TILE);
-  if (n_tiles == 0) return TJAMD_OK;
-  int grid = (int) std::min<long> (n_tiles, 256l * 8);
-  hipLaunchKernelGGL (scan_kernel<W>, dim3 (grid), dim3 (TJ_BLOCK), 0, c->stream, d_seq, (long) n_bytes, n_tiles, c->k, mprime,
-                      out, cap, ctr, (FixEntry *) c->fix.p, (u32) TJ_FIX_CAP);
-  HIPCHK (hipGetLastError ());
-  // non-ACGTU tracts (usually none): resolved against the stream, then the pending list is cleared
-  hipLaunchKernelGGL (nrun_fixup_kernel<W>, dim3 (64), dim3 (256), 0, c->stream, d_seq, (long) n_bytes, c->k, mprime,
-                      out, cap, ctr, (const FixEntry *) c->fix.p, (u32) TJ_FIX_CAP);
-  HIPCHK (hipGetLastError ());
-  HIPCHK (hipMemsetAsync (&ctr->n_fix, 0, sizeof (u64), c->stream));
-  c->last_scan_launches++;
+  if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
+  if (min_tract_size < 1 || min_tract_size > 32) return set_err (TJAMD_ERR_ARG, "min_tract_size %d outside [1,32] (reference clamp: src/main.c:186-187)", min_tract_size);
   return TJAMD_OK;
 }
 
 extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t n_bytes, int min_tract_size)
 {
-  if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
+  int rc = check_scan_args (c, min_tract_size);
+  if (rc) return rc;
   if (n_bytes == 0) return TJAMD_OK;
   if (!d_stream || ((uintptr_t) d_stream & 15u)) return set_err (TJAMD_ERR_ARG, "device stream pointer must be non-null and 16-byte aligned");
-  if (min_tract_size < 1 || min_tract_size > 32) return set_err (TJAMD_ERR_ARG, "min_tract_size %d outside [1,32] (reference clamp: src/main.c:186-187)", min_tract_size);
   HIPCHK (hipSetDevice (c->device));
   const int mprime = std::max (min_tract_size, 2);          // a tract needs two equal bytes: m = 1 behaves as m = 2
-  const long bound = (long) (n_bytes / (size_t) mprime) + 1; // tracts are disjoint runs of >= m' bytes
-  int rc = ensure (c->raw, (size_t) (c->n_raw_bound + bound) * 24, c->stream, (size_t) c->n_raw_bound * 24);
+  // tracts are disjoint runs of >= m' bytes: at most n/m' records come out of this batch
+  const u64 bound = (u64) ((double) (n_bytes / (size_t) mprime + 1) * c->slack);
+  rc = ensure_buckets (c, bound);
+  if (!rc) rc = ensure (c->fix, (size_t) TJ_FIX_CAP * sizeof (FixEntry), c->stream);
   if (rc) return rc;
-  c->n_raw_bound += bound;
+  const long n_tiles = (long) ((n_bytes + TJ_SB_TILE - 1) / TJ_SB_TILE);
+  const int grid = (int) std::min<long> (n_tiles, c->n_cu);
+  const uint8_t *seq = (const uint8_t *) d_stream;
+  const Buckets BK = make_buckets (c);
+  FixEntry *fix = (FixEntry *) c->fix.p;
   HIPCHK (hipEventRecord (c->ev_s0, c->stream));
-  c->last_scan_launches = 0;
-  rc = launch_scan<3> (c, (const uint8_t *) d_stream, n_bytes, mprime, (u64 *) c->raw.p, (u64) (c->raw.cap / 24), c->d_ctr);
-  if (rc) return rc;
+  switch (c->W) {
+    case 1:
+      hipLaunchKernelGGL (scan_bins_kernel<1>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP);
+      hipLaunchKernelGGL (nrun_fixup_bins_kernel<1>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP);
+      break;
+    case 2:
+      hipLaunchKernelGGL (scan_bins_kernel<2>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP);
+      hipLaunchKernelGGL (nrun_fixup_bins_kernel<2>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP);
+      break;
+    default:
+      hipLaunchKernelGGL (scan_bins_kernel<3>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP);
+      hipLaunchKernelGGL (nrun_fixup_bins_kernel<3>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP);
+      break;
+  }
+  HIPCHK (hipGetLastError ());
+  HIPCHK (hipMemsetAsync (&c->d_ctr->n_fix, 0, sizeof (u64), c->stream));
   HIPCHK (hipEventRecord (c->ev_s1, c->stream));
   c->scan_timed = true;
+  c->last_scan_launches = 1;
   c->status = -1;
   return TJAMD_OK;
 }
@@ -839,49 +1374,36 @@ extern "C" int tjamd_scan_host (tjamd_counter *c, const void *h_stream, size_t n
 extern "C" long tjamd_scan_host_located (tjamd_counter *c, const void *h_stream, size_t n_bytes, int min_tract_size,
                                           tjamd_located_record *out, long capacity)
 {
-  if (!c) return -set_err (TJAMD_ERR_ARG, "null counter");
-  if (min_tract_size < 1) return -set_err (TJAMD_ERR_ARG, "min_tract_size %d < 1", min_tract_size);
+  int rc = check_scan_args (c, min_tract_size);
+  if (rc) return -rc;
   if (n_bytes == 0) return 0;
   if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
   const int mprime = std::max (min_tract_size, 2);
   const long bound = (long) (n_bytes / (size_t) mprime) + 1;
-  int rc = ensure (c->stage, (n_bytes + 255) & ~(size_t) 255, c->stream);
+  rc = ensure (c->stage, (n_bytes + 255) & ~(size_t) 255, c->stream);
   if (!rc) rc = ensure (c->loc, (size_t) bound * 32, c->stream);
+  if (!rc) rc = ensure (c->fix, (size_t) TJ_FIX_CAP * sizeof (FixEntry), c->stream);
   if (rc) return -rc;
   if (hipMemcpyAsync (c->stage.p, h_stream, n_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
       hipMemsetAsync (c->d_lctr, 0, sizeof (DevCounters), c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy to device failed");
-  rc = launch_scan<4> (c, (const uint8_t *) c->stage.p, n_bytes, mprime, (u64 *) c->loc.p, (u64) bound, c->d_lctr);
-  if (rc) return -rc;
-  DevCounters h;
+  const long n_tiles = (long) ((n_bytes + 4095) / 4096);
+  hipLaunchKernelGGL (scan_list_kernel, dim3 ((unsigned) std::min<long> (n_tiles, 2048)), dim3 (256), 0, c->stream, (const uint8_t *) c->stage.p, (long) n_bytes,
+                      n_tiles, c->k, mprime, (u64 *) c->loc.p, (u64) bound, c->d_lctr, (FixEntry *) c->fix.p, (u32) TJ_FIX_CAP);
+  hipLaunchKernelGGL (nrun_fixup_list_kernel, dim3 (64), dim3 (256), 0, c->stream, (const uint8_t *) c->stage.p, (long) n_bytes, c->k, mprime,
+                      (u64 *) c->loc.p, (u64) bound, c->d_lctr, (const FixEntry *) c->fix.p, (u32) TJ_FIX_CAP);
+  if (hipGetLastError () != hipSuccess) return -set_err (TJAMD_ERR_HIP, "located scan launch failed");
   if (hipMemcpyAsync (c->h_ctr, c->d_lctr, sizeof (DevCounters), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "located scan failed: %s", hipGetErrorString (hipGetLastError ()));
-  h = *c->h_ctr;
+  const DevCounters h = *c->h_ctr;
   if (h.overflow || h.fix_overflow) return -set_err (TJAMD_ERR_CAPACITY, "located scan overflow");
   c->n_undefined += (long) h.n_undefined;
-  long n = (long) h.n_rec;
+  const long n = (long) h.n_rec;
   if (n > capacity) return -set_err (TJAMD_ERR_CAPACITY, "located scan produced %ld records, caller capacity %ld", n, capacity);
   if (n) {
     if (hipMemcpy (out, c->loc.p, (size_t) n * 32, hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "download failed");
     std::sort (out, out + n, [] (const tjamd_located_record &a, const tjamd_located_record &b) { return a.pos < b.pos; });
   }
   return n;
-}
-
-extern "C" void *tjamd_host_alloc (size_t bytes)
-{
-  void *p = nullptr;
-  if (hipHostMalloc (&p, bytes, hipHostMallocDefault) != hipSuccess) { set_err (TJAMD_ERR_HIP, "hipHostMalloc of %zu bytes failed", bytes); return NULL; }
-  return p;
-}
-
-extern "C" void tjamd_host_free (void *p) { if (p) (void) hipHostFree (p); }
-
-extern "C" int tjamd_sync (tjamd_counter *c)
-{
-  if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
-  HIPCHK (hipSetDevice (c->device));
-  HIPCHK (hipStreamSynchronize (c->stream));
-  return TJAMD_OK;
 }
 
 extern "C" long tjamd_raw_count (tjamd_counter *c)
@@ -903,7 +1425,22 @@ extern "C" long tjamd_download_raw (tjamd_counter *c, tjamd_record *out, long ca
   long n = tjamd_raw_count (c);
   if (n < 0) return n;
   if (n > capacity) return -set_err (TJAMD_ERR_CAPACITY, "%ld raw records, caller capacity %ld", n, capacity);
-  if (n && hipMemcpy (out, c->raw.p, (size_t) n * 24, hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "download failed");
+  if (n == 0) return 0;
+  std::vector<u64> prefix (TJ_P);
+  u64 run = 0;
+  for (int b = 0; b < TJ_P; b++) { prefix[b] = run; run += c->h_cursors[b]; }
+  int rc = ensure (c->prefix, TJ_P * 8, c->stream);
+  if (!rc) rc = ensure (c->rawlist, (size_t) n * 24, c->stream);
+  if (rc) return -rc;
+  if (hipMemcpyAsync (c->prefix.p, prefix.data (), TJ_P * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  const Buckets BK = make_buckets (c);
+  switch (c->W) {
+    case 1: hipLaunchKernelGGL (unpack_buckets_kernel<1>, dim3 (TJ_P), dim3 (256), 0, c->stream, BK, (const u64 *) c->prefix.p, c->k, (u64 *) c->rawlist.p); break;
+    case 2: hipLaunchKernelGGL (unpack_buckets_kernel<2>, dim3 (TJ_P), dim3 (256), 0, c->stream, BK, (const u64 *) c->prefix.p, c->k, (u64 *) c->rawlist.p); break;
+    default: hipLaunchKernelGGL (unpack_buckets_kernel<3>, dim3 (TJ_P), dim3 (256), 0, c->stream, BK, (const u64 *) c->prefix.p, c->k, (u64 *) c->rawlist.p); break;
+  }
+  if (hipGetLastError () != hipSuccess || hipStreamSynchronize (c->stream) != hipSuccess ||
+      hipMemcpy (out, c->rawlist.p, (size_t) n * 24, hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "raw download failed");
   return n;
 }
 
@@ -913,20 +1450,20 @@ extern "C" int tjamd_upload_raw (tjamd_counter *c, const hopo_element *elems, lo
   if (n == 0) return TJAMD_OK;
   HIPCHK (hipSetDevice (c->device));
   int rc = sync_counters (c);
-  if (rc) return rc;
-  rc = ensure (c->raw, (size_t) (c->n_raw_known + n) * 24, c->stream, (size_t) c->n_raw_known * 24);
+  if (!rc) rc = ensure_buckets (c, (u64) n);            // worst case: every record in one bucket
   if (!rc) rc = ensure (c->stage, (size_t) n * 40, c->stream);
   if (rc) return rc;
   HIPCHK (hipMemcpyAsync (c->stage.p, elems, (size_t) n * 40, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL (elem_to_record_kernel, dim3 ((unsigned) std::min<long> ((n + 255) / 256, 2048)), dim3 (256), 0, c->stream,
-                      (const u64 *) c->stage.p, n, (u64 *) c->raw.p + 3 * c->n_raw_known);
+  const unsigned grid = (unsigned) std::min<long> ((n + 255) / 256, 2048);
+  const Buckets BK = make_buckets (c);
+  switch (c->W) {
+    case 1: hipLaunchKernelGGL (bin_elems_kernel<1>, dim3 (grid), dim3 (256), 0, c->stream, (const u64 *) c->stage.p, n, c->k, BK, c->d_ctr); break;
+    case 2: hipLaunchKernelGGL (bin_elems_kernel<2>, dim3 (grid), dim3 (256), 0, c->stream, (const u64 *) c->stage.p, n, c->k, BK, c->d_ctr); break;
+    default: hipLaunchKernelGGL (bin_elems_kernel<3>, dim3 (grid), dim3 (256), 0, c->stream, (const u64 *) c->stage.p, n, c->k, BK, c->d_ctr); break;
+  }
   HIPCHK (hipGetLastError ());
-  c->h_ctr->n_rec = (u64) (c->n_raw_known + n);
-  HIPCHK (hipMemcpyAsync (&c->d_ctr->n_rec, &c->h_ctr->n_rec, sizeof (u64), hipMemcpyHostToDevice, c->stream));
-  HIPCHK (hipStreamSynchronize (c->stream));
-  c->n_raw_known += n; c->n_raw_bound = c->n_raw_known;
   c->status = -1;
-  return TJAMD_OK;
+  return sync_counters (c);
 }
 
 // ---- device-wide exclusive scan ------------------------------------------------------------------------------------
@@ -990,58 +1527,49 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   if (n == 0) { c->status = 1; if (status) *status = 1; return TJAMD_OK; }     // reference: src/hopo_counter.c:345-349
   if (n >= (1l << 31)) return set_err (TJAMD_ERR_CAPACITY, "%ld raw records exceed the reference's int n_elem", n);
 
+  // steps 1-2: per-bucket hash aggregation + filter (reference :351-374).  Distinct keys <= raw records.
+  rc = ensure (c->kept, (size_t) n * 24, c->stream);
+  if (rc) return rc;
   HIPCHK (hipEventRecord (c->ev_f0, c->stream));
-  rc = ensure (c->alt, (size_t) n * 24, c->stream);
-  if (!rc) rc = ensure (c->flags, (size_t) n * 4, c->stream);
-  if (!rc) rc = ensure (c->segid, (size_t) n * 4, c->stream);
-  if (!rc) rc = ensure (c->headpos, (size_t) n * 4, c->stream);
-  if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n) * 4, c->stream);
-  if (rc) return rc;
-
-  // step 1: sort (reference :351)
-  u64 *a = (u64 *) c->raw.p, *b = (u64 *) c->alt.p;
-  rc = radix_sort_records (c, a, b, n);
-  if (rc) return rc;
-  if (a != (u64 *) c->raw.p) std::swap (c->raw, c->alt);      // sorted records are the raw list again
-
-  // step 2: collapse equal keys, filter (reference :356-374)
-  u32 *flags = (u32 *) c->flags.p, *segid = (u32 *) c->segid.p, *headpos = (u32 *) c->headpos.p;
-  hipLaunchKernelGGL (seg_heads_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) a, n, flags, 0);
+  HIPCHK (hipMemsetAsync (c->d_fin, 0, sizeof (FinCounts), c->stream));
+  const Buckets BK = make_buckets (c);
+  switch (c->W) {
+    case 1: hipLaunchKernelGGL (aggregate_kernel<1>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
+    case 2: hipLaunchKernelGGL (aggregate_kernel<2>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
+    default: hipLaunchKernelGGL (aggregate_kernel<3>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
+  }
   HIPCHK (hipGetLastError ());
-  rc = exclusive_scan (c, flags, segid, n, &c->d_fin->n_seg, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
-  if (rc) return rc;
-  hipLaunchKernelGGL (seg_headpos_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u32 *) flags, (const u32 *) segid, n, headpos);
-  HIPCHK (hipGetLastError ());
-  // the number of runs is only known on the device: size by the bound n, kernels read the count
-  rc = ensure (c->keep, (size_t) n * 4, c->stream);
-  if (!rc) rc = ensure (c->outpos, (size_t) n * 4, c->stream);
-  if (!rc) rc = ensure (c->segmeta, (size_t) n * 8, c->stream);
+  // the aggregation consumed the buckets (leftover rounds reuse their fronts): the raw records are gone
+  rc = clear_buckets (c);
   if (rc) return rc;
   HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
   HIPCHK (hipStreamSynchronize (c->stream));
-  const long n_seg = c->h_fin->n_seg;
-  u32 *keep = (u32 *) c->keep.p, *outpos = (u32 *) c->outpos.p;
-  hipLaunchKernelGGL (seg_decide_kernel, dim3 (grid_for (n_seg)), dim3 (256), 0, c->stream, (const u64 *) a, n, (const u32 *) headpos,
-                      (const u32 *) &c->d_fin->n_seg, remove_biased, keep, (u64 *) c->segmeta.p);
-  HIPCHK (hipGetLastError ());
-  rc = exclusive_scan (c, keep, outpos, n_seg, &c->d_fin->n_kept, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
-  if (rc) return rc;
-  HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK (hipStreamSynchronize (c->stream));
+  if (c->h_fin->overflow) return set_err (TJAMD_ERR_CAPACITY, "kept list overflow");
   const long n1 = c->h_fin->n_kept;
   if (n1 == 0) {                                                               // reference :376-381
     HIPCHK (hipEventRecord (c->ev_f1, c->stream)); c->fin_timed = true;
     c->status = 2; if (status) *status = 2; return TJAMD_OK;
   }
-  rc = ensure (c->kept, (size_t) n1 * 24, c->stream);
+
+  // step 3: order the survivors as the reference's qsort does (base, ctx0, ctx1, length, all descending)
+  rc = ensure (c->alt, (size_t) n1 * 24, c->stream);
+  if (!rc) rc = ensure (c->flags, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->segid, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->headpos, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->keep, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->outpos, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n1) * 4, c->stream);
   if (rc) return rc;
-  hipLaunchKernelGGL (seg_write_kernel, dim3 (grid_for (n_seg)), dim3 (256), 0, c->stream, (const u64 *) a, (const u32 *) headpos,
-                      (const u32 *) &c->d_fin->n_seg, (const u32 *) keep, (const u32 *) outpos, (const u64 *) c->segmeta.p, (u64 *) c->kept.p);
-  HIPCHK (hipGetLastError ());
+  u64 *a = (u64 *) c->kept.p, *b = (u64 *) c->alt.p;
+  rc = radix_sort_records (c, a, b, n1);
+  if (rc) return rc;
+  if (a != (u64 *) c->kept.p) std::swap (c->kept, c->alt);
   c->n_kept = n1;
 
   // step 4: contexts deep enough get an index range (reference :388-404)
   const u64 *kept = (const u64 *) c->kept.p;
+  u32 *flags = (u32 *) c->flags.p, *segid = (u32 *) c->segid.p, *headpos = (u32 *) c->headpos.p;
+  u32 *keep = (u32 *) c->keep.p, *outpos = (u32 *) c->outpos.p;
   hipLaunchKernelGGL (seg_heads_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, kept, n1, flags, 1);
   HIPCHK (hipGetLastError ());
   rc = exclusive_scan (c, flags, segid, n1, &c->d_fin->n_ctx, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
