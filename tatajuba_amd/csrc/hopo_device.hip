@@ -85,6 +85,7 @@ struct DevCounters
   u64 n_rec;        // records appended to the located list
   u64 n_fix;        // pending non-ACGTU runs (see nrun_fixup kernels)
   u64 n_undefined;  // qualifying non-ACGTU runs without an earlier tract in the read (reference: uninitialised memory)
+  u64 n_null;       // padding records written into the buckets (reserved slots that stayed empty)
   u32 overflow;     // output list / a bucket too small
   u32 fix_overflow; // fix list too small
 };
@@ -318,6 +319,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     __syncthreads ();
 
     // ---- phase 3: one lane per candidate --------------------------------------------------------------------
+    sink.tick ();
     const int ncand = min ((int) T.ncand, G::MAXCAND);
     for (int cb0 = 0; cb0 < ncand; cb0 += BLOCK) {
       const int ci = cb0 + tid;
@@ -404,6 +406,7 @@ __device__ bool stale_context (const uint8_t *__restrict__ seq, long n_bytes, lo
 struct ListSink
 {
   u64 *out; u64 cap; DevCounters *ctr;
+  __device__ __forceinline__ void tick () {}
   __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos)
   {
     emit_record<4> (have, c0, c1, make_meta (base, len10, flag), pos, out, cap, ctr);
@@ -439,15 +442,17 @@ __global__ void nrun_fixup_list_kernel (const uint8_t *__restrict__ seq, long n_
 // Between the scan and the aggregation a raw tract is W 64-bit words, W chosen from k so that nothing is wasted:
 //   W = 1 (k <= 12): flag | len << 2 | ctx1 << 12 | ctx0 << (12 + 2k) | base << (12 + 4k)          (<= 61 bits)
 //   W = 2 (k <= 28): { ctx0 | len[7:0] << 56 ,  ctx1 | (len[9:8] | flag << 2 | base << 4) << 56 }
-//   W = 3          : { ctx0, ctx1, base | len << 2 | flag << 12 }
+//   W = 4          : { ctx0, ctx1, base | len << 2 | flag << 12, 0 }   (k > 28; padded so that 4 records fill a 128-byte line)
+// flag == 3 never occurs in a raw record (one tract, one strand): it marks a padding ("null") record.
 
 template <int W> __device__ __forceinline__ void pack_raw (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w);
 template <> __device__ __forceinline__ void pack_raw<1> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
 { w[0] = (u64) flag | ((u64) len10 << 2) | (c1 << 12) | (c0 << (12 + 2 * k)) | ((u64) base << (12 + 4 * k)); }
 template <> __device__ __forceinline__ void pack_raw<2> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
 { w[0] = c0 | ((u64) (len10 & 0xFFu) << 56); w[1] = c1 | ((u64) ((len10 >> 8) | (flag << 2) | (base << 4)) << 56); }
-template <> __device__ __forceinline__ void pack_raw<3> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
-{ w[0] = c0; w[1] = c1; w[2] = (u64) base | ((u64) len10 << 2) | ((u64) flag << 12); }
+template <> __device__ __forceinline__ void pack_raw<4> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
+{ w[0] = c0; w[1] = c1; w[2] = (u64) base | ((u64) len10 << 2) | ((u64) flag << 12); w[3] = 0; }
+template <int W> __device__ __forceinline__ void pack_null (u64 *w) { pack_raw<W> (0, 0, 0, 0, 3u, 2, w); }
 
 template <int W> __device__ __forceinline__ void unpack_raw (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag);
 template <> __device__ __forceinline__ void unpack_raw<1> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
@@ -461,10 +466,10 @@ template <> __device__ __forceinline__ void unpack_raw<2> (const u64 *w, int k, 
   const u32 hi = (u32) (w[1] >> 56);
   c0 = w[0] & m56; c1 = w[1] & m56; len10 = (u32) (w[0] >> 56) | ((hi & 3u) << 8); flag = (hi >> 2) & 3u; base = (hi >> 4) & 1u;
 }
-template <> __device__ __forceinline__ void unpack_raw<3> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
+template <> __device__ __forceinline__ void unpack_raw<4> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
 { c0 = w[0]; c1 = w[1]; base = (u32) (w[2] & 3ull); len10 = (u32) ((w[2] >> 2) & 0x3FFull); flag = (u32) ((w[2] >> 12) & 3ull); }
 
-// hash of the reduction key (base, context, stored length): bits 0-8 pick the bucket, 9-20 the table slot, 32-63 the tag
+// hash of the reduction key (base, context, stored length): bits 0-7 pick the bucket, 8-19 the table slot, 32-63 the tag
 __device__ __forceinline__ u64 hash_key (u64 c0, u64 c1, u32 base, u32 len10)
 {
   u64 h = (c0 + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
@@ -474,15 +479,18 @@ __device__ __forceinline__ u64 hash_key (u64 c0, u64 c1, u32 base, u32 len10)
   return h;
 }
 
-#define TJ_P        512                 // hash buckets
-#define TJ_BINWORDS 24                  // 64-bit words per LDS write-combining bin (192 bytes)
-#define TJ_CH0      1536                // chunk size unit in records (multiple of every bin's record count 24 / 12 / 8)
+#define TJ_P        256                 // hash buckets
+#define TJ_PBITS    8
+#define TJ_BINWORDS 16                  // 64-bit words per LDS write-combining bin: one 128-byte line
+#define TJ_CH0      1536                // chunk size unit in records (multiple of every bin's record count 16 / 8 / 4)
 #define TJ_EMPTY    0xFFFFFFFFu
 
-// Bucket storage.  A bucket is a sequence of records numbered by its cursor; record `pos` lives in the bucket's
-// (pos / CH)-th chunk.  Chunks come from one pool and are claimed on first touch by a compare-and-swap on the
-// bucket's chunk table (a lost race only leaks the loser's chunk), so a skewed hash distribution costs nothing:
-// memory follows the data, not the worst bucket.
+// Bucket storage.  A bucket is a sequence of records numbered by its cursor, handed out in blocks of one bin (C
+// records = 128 bytes, so a block never straddles anything); record `pos` lives in the bucket's (pos / CH)-th chunk.
+// Chunks come from one pool: chunk 0 of every bucket is assigned by the host, and the thread that reserves the FIRST
+// block of chunk j takes chunk j + 1 from the pool and publishes it in the bucket's table -- a whole chunk before anybody
+// needs it, so nobody waits in practice, nothing leaks, and a skewed hash distribution costs nothing: memory follows
+// the data, not the fullest bucket.
 struct Buckets
 {
   u64 *pool;          // pool_chunks * CH * W words
@@ -497,27 +505,22 @@ struct Buckets
 
 __device__ __forceinline__ u32 chunk_of_pos (const Buckets &B, u32 pos) { return (pos / TJ_CH0) >> B.ch_shift; }
 
-// The reservation [p0, p0 + n) of bucket b (n <= 24): if it holds the FIRST record of a chunk, take a chunk from the
-// pool and publish it in the bucket's table.  Exactly one reservation holds that record, so exactly one thread claims
-// each chunk; everybody else waits for the entry in bucket_slot().  Call it right after reserving, before any wait.
-__device__ __forceinline__ void bucket_claim (const Buckets &B, u32 b, u32 p0, u32 n, DevCounters *ctr)
+// Called by whoever reserved the block starting at p0: if that block opens chunk j, claim chunk j + 1.
+__device__ __forceinline__ void bucket_claim_ahead (const Buckets &B, u32 b, u32 p0, DevCounters *ctr)
 {
-  const u32 j = chunk_of_pos (B, p0 + n - 1);
-  const u32 first = (j * TJ_CH0) << B.ch_shift;
-  if (first < p0) return;                               // the chunk was started by an earlier reservation
-  if (j >= B.maxj) { ctr->overflow = 1u; return; }
+  const u32 j = chunk_of_pos (B, p0);
+  if (p0 != ((j * TJ_CH0) << B.ch_shift)) return;
+  if (j + 1 >= B.maxj) { ctr->overflow = 1u; return; }
   const u32 mine = atomicAdd (B.pool_next, 1u);
   if (mine >= B.pool_chunks) ctr->overflow = 1u;
-  __hip_atomic_store (B.table + (u64) b * B.maxj + j, mine < B.pool_chunks ? mine : TJ_NOCHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store (B.table + (u64) b * B.maxj + j + 1, mine < B.pool_chunks ? mine : TJ_NOCHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// index (in records) inside the pool of record `pos` of bucket b; ~0 if it has no storage.  wait = the chunk may still
-// be in the hands of the thread that claims it (same launch): poll the table entry, bounded.
-__device__ __forceinline__ u64 bucket_slot (const Buckets &B, u32 b, u32 pos, bool wait, DevCounters *ctr)
+// chunk id of the j-th chunk of bucket b (TJ_NOCHUNK if it has none).  wait = the entry may still be on its way from
+// the thread that claims it (same launch): poll it, bounded.
+__device__ __forceinline__ u32 bucket_chunk_id (const Buckets &B, u32 b, u32 j, bool wait, DevCounters *ctr)
 {
-  const u32 j = chunk_of_pos (B, pos);
-  const u32 off = pos - ((j * TJ_CH0) << B.ch_shift);
-  if (j >= B.maxj) return ~0ull;
+  if (j >= B.maxj) return TJ_NOCHUNK;
   u32 *e = B.table + (u64) b * B.maxj + j;
   u32 ch = __hip_atomic_load (e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (wait) {
@@ -527,20 +530,35 @@ __device__ __forceinline__ u64 bucket_slot (const Buckets &B, u32 b, u32 pos, bo
     }
     if (ch == TJ_EMPTY && ctr) ctr->overflow = 1u;
   }
-  if (ch >= TJ_NOCHUNK) return ~0ull;
-  return (((u64) ch * TJ_CH0) << B.ch_shift) + off;
+  return ch >= TJ_NOCHUNK ? TJ_NOCHUNK : ch;
+}
+
+// index (in records) inside the pool of record `pos` of bucket b; ~0 if it has no storage
+__device__ __forceinline__ u64 bucket_slot (const Buckets &B, u32 b, u32 pos, bool wait, DevCounters *ctr)
+{
+  const u32 j = chunk_of_pos (B, pos);
+  const u32 ch = bucket_chunk_id (B, b, j, wait, ctr);
+  if (ch == TJ_NOCHUNK) return ~0ull;
+  return (((u64) ch * TJ_CH0) << B.ch_shift) + (pos - ((j * TJ_CH0) << B.ch_shift));
 }
 
 template <int W>
 __device__ __forceinline__ void bucket_insert_slow (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, const Buckets &B, DevCounters *ctr)
-{
-  u64 w[W];
+{ // a whole block for one record (cursors stay multiples of the block size); the rest is padding
+  constexpr int C = TJ_BINWORDS / W;
+  u64 w[W], z[W];
   pack_raw<W> (c0, c1, base, len10, flag, k, w);
+  pack_null<W> (z);
   const u32 b = (u32) hash_key (c0, c1, base, len10) & (TJ_P - 1);
-  const u32 pos = atomicAdd (&B.cursors[b], 1u);
-  bucket_claim (B, b, pos, 1u, ctr);
+  const u32 pos = atomicAdd (&B.cursors[b], (u32) C);
+  bucket_claim_ahead (B, b, pos, ctr);
   const u64 at = bucket_slot (B, b, pos, true, ctr);
-  if (at != ~0ull) { u64 *q = B.pool + at * W; for (int j = 0; j < W; j++) q[j] = w[j]; }
+  if (at != ~0ull) {
+    u64 *q = B.pool + at * W;
+    for (int j = 0; j < W; j++) q[j] = w[j];
+    for (int r = 1; r < C; r++) for (int j = 0; j < W; j++) q[r * W + j] = z[j];
+    atomicAdd (&ctr->n_null, (u64) (C - 1));
+  }
 }
 
 // ---- sink 2: hash-partition into TJ_P buckets through LDS write-combining bins --------------------------------------
@@ -552,16 +570,50 @@ struct BinLds
   u64 gpos[TJ_P];
   u32 cnt[TJ_P];
   u32 list[TJ_P];
-  u32 p0[TJ_P];
-  u32 nfull;
+  u32 nfull, nnull;
 };
 
+// Thread t < TJ_P owns bin t of its workgroup.  It always holds one block of bucket t reserved in advance (`next`, the
+// result of an atomic issued at the previous flush, so its latency is never waited for) and remembers the chunk it is
+// writing to, so a flush is an LDS -> HBM copy of one 128-byte line with no global round trip on the critical path.
 template <int W, int BLOCK>
 struct BinSink
 {
-  static constexpr int C = TJ_BINWORDS / W;             // records per bin: 24, 12, 8
+  static constexpr int C = TJ_BINWORDS / W;             // records per bin: 16, 8, 4
   BinLds<W> &L;
   Buckets B; DevCounters *ctr; int k;
+  u32 next, cur_j, cur_chunk;                           // owner-thread state (registers)
+  bool unclaimed;                                       // `next` was reserved but its chunk-ahead claim is still due
+
+  __device__ __forceinline__ void start ()
+  {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TJ_P; i += BLOCK) L.cnt[i] = 0;
+    if (tid == 0) { L.nfull = 0; L.nnull = 0; }
+    cur_j = TJ_EMPTY; cur_chunk = 0; next = 0; unclaimed = false;
+    if (tid < TJ_P) { next = atomicAdd (&B.cursors[tid], (u32) C); bucket_claim_ahead (B, (u32) tid, next, ctr); }
+    __syncthreads ();
+  }
+
+  // Once per tile: a reservation made at the last flush has returned by now; if it opened a chunk, claim the next one.
+  // Claims therefore never wait for a bin to fill (other workgroups may already be writing past that chunk).
+  __device__ __forceinline__ void tick ()
+  {
+    if (unclaimed) { bucket_claim_ahead (B, (u32) threadIdx.x, next, ctr); unclaimed = false; }
+  }
+
+  // pool index of the owner's reserved block; reserves the following one
+  __device__ __forceinline__ u64 take_block (bool reserve_more)
+  {
+    const int tid = threadIdx.x;
+    const u32 p0 = next;
+    tick ();
+    if (reserve_more) { next = atomicAdd (&B.cursors[tid], (u32) C); unclaimed = true; }
+    const u32 j = chunk_of_pos (B, p0);
+    if (j != cur_j) { cur_j = j; cur_chunk = bucket_chunk_id (B, (u32) tid, j, true, ctr); }   // first block here: look the chunk up
+    if (cur_chunk >= TJ_NOCHUNK) return ~0ull;
+    return (((u64) cur_chunk * TJ_CH0) << B.ch_shift) + (p0 - ((j * TJ_CH0) << B.ch_shift));
+  }
 
   __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos)
   {
@@ -583,26 +635,11 @@ struct BinSink
       const int anyp = __syncthreads_or (pending ? 1 : 0);
       const bool full = (tid < TJ_P) && (L.cnt[tid] >= (u32) C);
       const int nfull = __syncthreads_count (full ? 1 : 0);
-      if (nfull) {                                      // write every full bin as one 192-byte piece of its bucket
+      if (nfull) {                                      // every full bin goes out as one 128-byte line of its bucket
         if (full) {
-          const u32 at = atomicAdd (&L.nfull, 1u);
-          L.list[at] = (u32) tid;
-          const u32 p0 = atomicAdd (&B.cursors[tid], (u32) C);
-          bucket_claim (B, (u32) tid, p0, (u32) C, ctr);
-          L.p0[tid] = p0;
+          L.list[atomicAdd (&L.nfull, 1u)] = (u32) tid;
+          L.gpos[tid] = take_block (true);
           L.cnt[tid] = 0;
-        }
-        __syncthreads ();                               // every claim of this workgroup is out before anybody waits
-        if (full) {
-          const u32 p0 = L.p0[tid];
-          if (chunk_of_pos (B, p0) == chunk_of_pos (B, p0 + C - 1)) L.gpos[tid] = bucket_slot (B, (u32) tid, p0, true, ctr);
-          else {                                        // the piece straddles two chunks (rare): record by record
-            L.gpos[tid] = ~0ull;
-            for (int r = 0; r < C; r++) {
-              const u64 g = bucket_slot (B, (u32) tid, p0 + r, true, ctr);
-              if (g != ~0ull) for (int j = 0; j < W; j++) B.pool[g * W + j] = L.bins[tid * TJ_BINWORDS + r * W + j];
-            }
-          }
         }
         __syncthreads ();
         for (int i = tid; i < nfull * TJ_BINWORDS; i += BLOCK) {
@@ -619,37 +656,40 @@ struct BinSink
   }
 
   __device__ __forceinline__ void finish ()
-  { // partial bins at the end of the workgroup's life
+  { // the reserved block of every bin takes what is left in the bin, padded with null records
     const int tid = threadIdx.x;
+    tick ();
     __syncthreads ();
     if (tid < TJ_P) {
       const u32 n = min (L.cnt[tid], (u32) C);
-      if (n) {                                          // record by record: the tail may cross into a new chunk
-        const u32 p0 = atomicAdd (&B.cursors[tid], n);
-        bucket_claim (B, (u32) tid, p0, n, ctr);
-        for (u32 r = 0; r < n; r++) {
-          const u64 g = bucket_slot (B, (u32) tid, p0 + r, true, ctr);
-          if (g != ~0ull) for (int j = 0; j < W; j++) B.pool[g * W + j] = L.bins[tid * TJ_BINWORDS + r * W + j];
-        }
+      const u64 g = take_block (false);
+      if (g != ~0ull) {
+        u64 z[W];
+        pack_null<W> (z);
+        u64 *q = B.pool + g * W;
+        for (u32 i = 0; i < n * W; i++) q[i] = L.bins[tid * TJ_BINWORDS + i];
+        for (u32 r = n; r < (u32) C; r++) for (int j = 0; j < W; j++) q[r * W + j] = z[j];
+        atomicAdd (&L.nnull, (u32) C - n);
       }
     }
+    __syncthreads ();
+    if (tid == 0 && L.nnull) atomicAdd (&ctr->n_null, (u64) L.nnull);
   }
 };
 
-#define TJ_SB_BLOCK 1024
-#define TJ_SB_TILE  16384
+#define TJ_SB_BLOCK 512
+#define TJ_SB_TILE  8192
+#define TJ_SB_WG_PER_CU 3               // ~50 KB of LDS and <= 80 VGPRs per workgroup
 
 template <int W>
-__global__ __launch_bounds__ (TJ_SB_BLOCK)
+__global__ __launch_bounds__ (TJ_SB_BLOCK, 6)
 void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
                        Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
 {
   __shared__ TileLds<TJ_SB_BLOCK, TJ_SB_TILE> T;
   __shared__ BinLds<W> B;
-  for (int i = threadIdx.x; i < TJ_P; i += TJ_SB_BLOCK) B.cnt[i] = 0;
-  if (threadIdx.x == 0) B.nfull = 0;
-  __syncthreads ();
-  BinSink<W, TJ_SB_BLOCK> sink = {B, BK, ctr, k};
+  BinSink<W, TJ_SB_BLOCK> sink = {B, BK, ctr, k, 0u, 0u, 0u, false};
+  sink.start ();
   scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE> (seq, n_bytes, n_tiles, k, mprime, T, sink, ctr, fix, fix_cap);
   sink.finish ();
 }
@@ -679,9 +719,9 @@ __global__ void bin_elems_kernel (const u64 *__restrict__ elems5, long n, int k,
   }
 }
 
-// buckets -> flat list of 24-byte raw records (test aid)
+// buckets -> flat list of 24-byte raw records, padding skipped (test aid; order is irrelevant)
 template <int W>
-__global__ void unpack_buckets_kernel (Buckets BK, const u64 *__restrict__ prefix, int k, u64 *__restrict__ out)
+__global__ void unpack_buckets_kernel (Buckets BK, int k, u64 *__restrict__ out, u64 cap, u64 *n_out)
 {
   const u32 b = blockIdx.x;
   const u32 n = BK.cursors[b];
@@ -690,9 +730,18 @@ __global__ void unpack_buckets_kernel (Buckets BK, const u64 *__restrict__ prefi
     const u64 at = bucket_slot (BK, b, i, false, nullptr);
     if (at == ~0ull) continue;
     unpack_raw<W> (BK.pool + at * W, k, c0, c1, base, len10, flag);
-    u64 *q = out + 3 * (prefix[b] + i);
-    q[0] = c0; q[1] = c1; q[2] = make_meta (base, len10, flag);
+    if (flag == 3u) continue;
+    const u64 o = atomicAdd (n_out, 1ull);
+    if (o < cap) { u64 *q = out + 3 * o; q[0] = c0; q[1] = c1; q[2] = make_meta (base, len10, flag); }
   }
+}
+
+// chunk 0 of every bucket
+__global__ void init_table_kernel (u32 *table, u32 maxj, u32 *pool_next)
+{
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < TJ_P) table[(u64) b * maxj] = b;
+  if (b == 0) *pool_next = TJ_P;
 }
 
 // chunk table with a longer row
@@ -731,7 +780,7 @@ struct AggLds
 __device__ __forceinline__ bool agg_insert (AggLds &L, u64 c0, u64 c1, u32 k2, u32 flag, u64 h, bool closed)
 { // true = counted; false = key absent from a closed table
   const u32 mytag = ((u32) (h >> 32) & ~3u) | 1u;
-  u32 slot = (u32) (h >> 9) & (AG_S - 1);
+  u32 slot = (u32) (h >> TJ_PBITS) & (AG_S - 1);
   for (u32 probes = 0; probes < AG_S;) {
     u32 t;
     if (!closed) {
@@ -773,27 +822,34 @@ void aggregate_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ k
     if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.closed = 0; }
     __syncthreads ();
 
-    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK) {
-      const u32 idx = b0 + tid;
-      const bool have = idx < n;
-      u64 w[W];
-      bool valid = false;
-      if (have) {
+    u64 wn[W];                                          // records are fetched one batch ahead of their use
+    bool vn = false;
+    auto fetch = [&] (u32 idx) {
+      vn = false;
+      if (idx < n) {
         const u64 at = bucket_slot (BK, bkt, idx, false, nullptr);
-        valid = at != ~0ull;                            // (a record that could not be placed was already reported)
-        if (valid) {
+        if (at != ~0ull) {
+          vn = true;
 #pragma unroll
-          for (int j = 0; j < W; j++) w[j] = BK.pool[at * W + j];
+          for (int j = 0; j < W; j++) wn[j] = BK.pool[at * W + j];
         }
       }
+    };
+    fetch ((u32) tid);
+    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK) {
+      u64 w[W];
+#pragma unroll
+      for (int j = 0; j < W; j++) w[j] = wn[j];
+      const bool valid = vn;
+      fetch (b0 + AG_BLOCK + tid);                      // leftovers are written below b0 + AG_BLOCK: never where this reads
       if (tid == 0) L.closed = (L.n_claimed > AG_CLOSE_AT) ? 1u : 0u;
-      __syncthreads ();                                 // batch is in registers; table state decided for the batch
+      __syncthreads ();                                 // table state decided for the batch
       const bool closed = L.closed != 0u;
       if (valid) {
         u64 c0, c1; u32 base, len10, flag;
         unpack_raw<W> (w, k, c0, c1, base, len10, flag);
-        if (!agg_insert (L, c0, c1, base | (len10 << 2), flag, hash_key (c0, c1, base, len10), closed)) {
-          const u32 o = atomicAdd (&L.n_ovf, 1u);        // o <= records read so far: never ahead of the reads
+        if (flag != 3u && !agg_insert (L, c0, c1, base | (len10 << 2), flag, hash_key (c0, c1, base, len10), closed)) {
+          const u32 o = atomicAdd (&L.n_ovf, 1u);        // o <= records consumed so far: never ahead of the reads
           const u64 at = bucket_slot (BK, bkt, o, false, nullptr);
           if (at != ~0ull) {
 #pragma unroll
@@ -1073,13 +1129,20 @@ __global__ void cov_insert_kernel (const u64 *__restrict__ kept, long n1, u32 *_
   }
 }
 
-__global__ void cov_max_kernel (const u32 *__restrict__ keys, const int *__restrict__ sums, long t, int *result)
+__global__ __launch_bounds__ (256)
+void cov_max_kernel (const u32 *__restrict__ keys, const int *__restrict__ sums, long t, int *result)
 {
+  __shared__ int s_best[4];
   int best = INT_MIN;
   for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < t; i += (long) gridDim.x * blockDim.x)
     if (keys[i] != 0xFFFFFFFFu) best = max (best, sums[i]);
   for (int o = 32; o > 0; o >>= 1) best = max (best, __shfl_down (best, o));
-  if ((threadIdx.x & 63) == 0 && best != INT_MIN) atomicMax (result, best);
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    best = max (max (s_best[0], s_best[1]), max (s_best[2], s_best[3]));
+    if (best != INT_MIN) atomicMax (result, best);      // one atomic per workgroup
+  }
 }
 
 __global__ void set_int_kernel (int *p, int v) { *p = v; }
@@ -1096,7 +1159,7 @@ struct DevBuf
 
 struct tjamd_counter
 {
-  int device = 0, k = 0, W = 3, n_cu = 256;
+  int device = 0, k = 0, W = 4, n_cu = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
   DevCounters *d_ctr = nullptr, *h_ctr = nullptr;     // scan counters (device / pinned host mirror)
   DevCounters *d_lctr = nullptr;                      // located-list counters
@@ -1145,7 +1208,7 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   HIPCHK_NULL (hipSetDevice (device));
   tjamd_counter *c = new tjamd_counter ();
   c->device = device; c->k = kmer_size;
-  c->W = (kmer_size <= 12) ? 1 : (kmer_size <= 28) ? 2 : 3;
+  c->W = (kmer_size <= 12) ? 1 : (kmer_size <= 28) ? 2 : 4;
   hipDeviceProp_t prop;
   HIPCHK_NULL (hipGetDeviceProperties (&prop, device));
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1215,8 +1278,13 @@ static Buckets make_buckets (const tjamd_counter *c)
 static int clear_buckets (tjamd_counter *c)
 {
   HIPCHK (hipMemsetAsync (c->d_cursors, 0, (TJ_P + 1) * sizeof (u32), c->stream));
-  if (c->table.p && c->maxj) HIPCHK (hipMemsetAsync (c->table.p, 0xFF, (size_t) TJ_P * c->maxj * 4, c->stream));
-  c->n_raw_known = 0; c->bucket_bound = 0; c->chunk_bound = 0; c->ch_shift = -1;
+  HIPCHK (hipMemsetAsync (&c->d_ctr->n_null, 0, sizeof (u64), c->stream));
+  if (c->table.p && c->maxj) {
+    HIPCHK (hipMemsetAsync (c->table.p, 0xFF, (size_t) TJ_P * c->maxj * 4, c->stream));
+    hipLaunchKernelGGL (init_table_kernel, dim3 (1), dim3 (TJ_P), 0, c->stream, (u32 *) c->table.p, c->maxj, c->d_cursors + TJ_P);
+    HIPCHK (hipGetLastError ());
+  }
+  c->n_raw_known = 0; c->bucket_bound = 0; c->chunk_bound = TJ_P; c->ch_shift = -1;
   return TJAMD_OK;
 }
 
@@ -1263,15 +1331,15 @@ static int sync_counters (tjamd_counter *c)
                     "raise TATAJUBA_AMD_BUCKET_SLACK (now %.1f) and scan again", c->h_cursors[TJ_P], c->pool_chunks, (unsigned long long) mx, c->slack);
   if (c->h_ctr->fix_overflow) return set_err (TJAMD_ERR_CAPACITY, "too many non-ACGTU tract candidates in one batch (%llu)",
                                              (unsigned long long) c->h_ctr->n_fix);
-  c->n_raw_known = total;
+  c->n_raw_known = total - (long) c->h_ctr->n_null;
   c->bucket_bound = mx;
   c->chunk_bound = c->h_cursors[TJ_P];
   c->n_undefined = (long) c->h_ctr->n_undefined;
   return TJAMD_OK;
 }
 
-// room for `add` more raw records (an upper bound), wherever the hash sends them
-static int ensure_buckets (tjamd_counter *c, u64 add)
+// room for `add` more raw records (an upper bound), wherever the hash sends them, written by `grid` workgroups
+static int ensure_buckets (tjamd_counter *c, u64 add, int grid)
 {
   if (c->ch_shift < 0) {                                // chunk size: at most ~16 k chunks for this many records
     const u64 units = add / (16384ull * TJ_CH0);
@@ -1280,9 +1348,10 @@ static int ensure_buckets (tjamd_counter *c, u64 add)
     c->ch_shift = sft;
   }
   const u64 ch = (u64) TJ_CH0 << c->ch_shift;
-  // every bucket may open one more chunk than its records need; claims never leak (one claimer per chunk)
-  const u64 need_chunks = c->chunk_bound + (add + ch - 1) / ch + TJ_P;
-  const u64 need_maxj = (c->bucket_bound + add + ch - 1) / ch + 2;      // worst case: everything hashes to one bucket
+  const u64 pad_bucket = (u64) grid * TJ_BINWORDS;      // each workgroup leaves at most one block per bucket partly empty
+  // one chunk per bucket is always claimed ahead of the cursor
+  const u64 need_chunks = c->chunk_bound + (add + pad_bucket * TJ_P + ch - 1) / ch + 2 * TJ_P;
+  const u64 need_maxj = (c->bucket_bound + add + pad_bucket + ch - 1) / ch + 3;   // worst case: everything in one bucket
   if (need_chunks >= TJ_NOCHUNK || need_maxj >= (1ull << 31)) return set_err (TJAMD_ERR_CAPACITY, "batch too large for the chunk table");
   int rc = ensure (c->pool, (size_t) need_chunks * ch * c->W * 8, c->stream, std::min<size_t> ((size_t) (c->chunk_bound * ch * c->W * 8), c->pool.cap));
   if (rc) return rc;
@@ -1293,6 +1362,10 @@ static int ensure_buckets (tjamd_counter *c, u64 add)
     hipError_t e = hipMalloc (&np, (size_t) TJ_P * nmaxj * 4);
     if (e != hipSuccess) return set_err (TJAMD_ERR_HIP, "hipMalloc of the chunk table failed: %s", hipGetErrorString (e));
     HIPCHK (hipMemsetAsync (np, 0xFF, (size_t) TJ_P * nmaxj * 4, c->stream));
+    if (!c->table.p || !c->maxj) {
+      hipLaunchKernelGGL (init_table_kernel, dim3 (1), dim3 (TJ_P), 0, c->stream, (u32 *) np, nmaxj, c->d_cursors + TJ_P);
+      HIPCHK (hipGetLastError ());
+    }
     if (c->table.p) {
       if (c->maxj) {
         hipLaunchKernelGGL (table_relayout_kernel, dim3 (TJ_P), dim3 (256), 0, c->stream, (const u32 *) c->table.p, c->maxj, (u32 *) np, nmaxj);
@@ -1304,7 +1377,7 @@ static int ensure_buckets (tjamd_counter *c, u64 add)
     c->table.p = np; c->table.cap = (size_t) TJ_P * nmaxj * 4; c->maxj = nmaxj;
   }
   c->chunk_bound = need_chunks;
-  c->bucket_bound += add;
+  c->bucket_bound += add + pad_bucket;
   return TJAMD_OK;
 }
 
@@ -1327,11 +1400,11 @@ extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t
   const int mprime = std::max (min_tract_size, 2);          // a tract needs two equal bytes: m = 1 behaves as m = 2
   // tracts are disjoint runs of >= m' bytes: at most n/m' records come out of this batch
   const u64 bound = (u64) ((double) (n_bytes / (size_t) mprime + 1) * c->slack);
-  rc = ensure_buckets (c, bound);
+  const long n_tiles = (long) ((n_bytes + TJ_SB_TILE - 1) / TJ_SB_TILE);
+  const int grid = (int) std::min<long> (n_tiles, (long) c->n_cu * TJ_SB_WG_PER_CU);
+  rc = ensure_buckets (c, bound, grid + 1);             // + the fix-up kernel's block-per-record inserts
   if (!rc) rc = ensure (c->fix, (size_t) TJ_FIX_CAP * sizeof (FixEntry), c->stream);
   if (rc) return rc;
-  const long n_tiles = (long) ((n_bytes + TJ_SB_TILE - 1) / TJ_SB_TILE);
-  const int grid = (int) std::min<long> (n_tiles, c->n_cu);
   const uint8_t *seq = (const uint8_t *) d_stream;
   const Buckets BK = make_buckets (c);
   FixEntry *fix = (FixEntry *) c->fix.p;
@@ -1346,8 +1419,8 @@ extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t
       hipLaunchKernelGGL (nrun_fixup_bins_kernel<2>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP);
       break;
     default:
-      hipLaunchKernelGGL (scan_bins_kernel<3>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP);
-      hipLaunchKernelGGL (nrun_fixup_bins_kernel<3>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP);
+      hipLaunchKernelGGL (scan_bins_kernel<4>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP);
+      hipLaunchKernelGGL (nrun_fixup_bins_kernel<4>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP);
       break;
   }
   HIPCHK (hipGetLastError ());
@@ -1426,21 +1499,21 @@ extern "C" long tjamd_download_raw (tjamd_counter *c, tjamd_record *out, long ca
   if (n < 0) return n;
   if (n > capacity) return -set_err (TJAMD_ERR_CAPACITY, "%ld raw records, caller capacity %ld", n, capacity);
   if (n == 0) return 0;
-  std::vector<u64> prefix (TJ_P);
-  u64 run = 0;
-  for (int b = 0; b < TJ_P; b++) { prefix[b] = run; run += c->h_cursors[b]; }
-  int rc = ensure (c->prefix, TJ_P * 8, c->stream);
+  int rc = ensure (c->prefix, 64, c->stream);
   if (!rc) rc = ensure (c->rawlist, (size_t) n * 24, c->stream);
   if (rc) return -rc;
-  if (hipMemcpyAsync (c->prefix.p, prefix.data (), TJ_P * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  if (hipMemsetAsync (c->prefix.p, 0, 8, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "memset failed");
   const Buckets BK = make_buckets (c);
   switch (c->W) {
-    case 1: hipLaunchKernelGGL (unpack_buckets_kernel<1>, dim3 (TJ_P), dim3 (256), 0, c->stream, BK, (const u64 *) c->prefix.p, c->k, (u64 *) c->rawlist.p); break;
-    case 2: hipLaunchKernelGGL (unpack_buckets_kernel<2>, dim3 (TJ_P), dim3 (256), 0, c->stream, BK, (const u64 *) c->prefix.p, c->k, (u64 *) c->rawlist.p); break;
-    default: hipLaunchKernelGGL (unpack_buckets_kernel<3>, dim3 (TJ_P), dim3 (256), 0, c->stream, BK, (const u64 *) c->prefix.p, c->k, (u64 *) c->rawlist.p); break;
+    case 1: hipLaunchKernelGGL (unpack_buckets_kernel<1>, dim3 (TJ_P), dim3 (256), 0, c->stream, BK, c->k, (u64 *) c->rawlist.p, (u64) n, (u64 *) c->prefix.p); break;
+    case 2: hipLaunchKernelGGL (unpack_buckets_kernel<2>, dim3 (TJ_P), dim3 (256), 0, c->stream, BK, c->k, (u64 *) c->rawlist.p, (u64) n, (u64 *) c->prefix.p); break;
+    default: hipLaunchKernelGGL (unpack_buckets_kernel<4>, dim3 (TJ_P), dim3 (256), 0, c->stream, BK, c->k, (u64 *) c->rawlist.p, (u64) n, (u64 *) c->prefix.p); break;
   }
+  u64 n_out = 0;
   if (hipGetLastError () != hipSuccess || hipStreamSynchronize (c->stream) != hipSuccess ||
+      hipMemcpy (&n_out, c->prefix.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
       hipMemcpy (out, c->rawlist.p, (size_t) n * 24, hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "raw download failed");
+  if ((long) n_out != n) return -set_err (TJAMD_ERR_STATE, "raw download found %llu records, cursors say %ld", (unsigned long long) n_out, n);
   return n;
 }
 
@@ -1450,7 +1523,7 @@ extern "C" int tjamd_upload_raw (tjamd_counter *c, const hopo_element *elems, lo
   if (n == 0) return TJAMD_OK;
   HIPCHK (hipSetDevice (c->device));
   int rc = sync_counters (c);
-  if (!rc) rc = ensure_buckets (c, (u64) n);            // worst case: every record in one bucket
+  if (!rc) rc = ensure_buckets (c, (u64) n * TJ_BINWORDS, 0);   // one block per record
   if (!rc) rc = ensure (c->stage, (size_t) n * 40, c->stream);
   if (rc) return rc;
   HIPCHK (hipMemcpyAsync (c->stage.p, elems, (size_t) n * 40, hipMemcpyHostToDevice, c->stream));
@@ -1459,7 +1532,7 @@ extern "C" int tjamd_upload_raw (tjamd_counter *c, const hopo_element *elems, lo
   switch (c->W) {
     case 1: hipLaunchKernelGGL (bin_elems_kernel<1>, dim3 (grid), dim3 (256), 0, c->stream, (const u64 *) c->stage.p, n, c->k, BK, c->d_ctr); break;
     case 2: hipLaunchKernelGGL (bin_elems_kernel<2>, dim3 (grid), dim3 (256), 0, c->stream, (const u64 *) c->stage.p, n, c->k, BK, c->d_ctr); break;
-    default: hipLaunchKernelGGL (bin_elems_kernel<3>, dim3 (grid), dim3 (256), 0, c->stream, (const u64 *) c->stage.p, n, c->k, BK, c->d_ctr); break;
+    default: hipLaunchKernelGGL (bin_elems_kernel<4>, dim3 (grid), dim3 (256), 0, c->stream, (const u64 *) c->stage.p, n, c->k, BK, c->d_ctr); break;
   }
   HIPCHK (hipGetLastError ());
   c->status = -1;
@@ -1536,7 +1609,7 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   switch (c->W) {
     case 1: hipLaunchKernelGGL (aggregate_kernel<1>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
     case 2: hipLaunchKernelGGL (aggregate_kernel<2>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
-    default: hipLaunchKernelGGL (aggregate_kernel<3>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
+    default: hipLaunchKernelGGL (aggregate_kernel<4>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
   }
   HIPCHK (hipGetLastError ());
   // the aggregation consumed the buckets (leftover rounds reuse their fronts): the raw records are gone
