@@ -72,11 +72,13 @@ struct TileLds
   static constexpr int CODEW = WIN / 16 + 4;             // words of 2-bit codes (+ pad)
   static constexpr int MAXCAND = TILE / 2;               // tracts have >= 2 bases: at most one candidate per 2 bytes
   static constexpr int NLOAD = (NCHUNK + BLOCK - 1) / BLOCK;
+  uint4 raw[2][NCHUNK];                                  // next tile's bytes land here straight from HBM (LDS-DMA)
   u32 code[CODEW];
   u32 start[MASKW];
   u32 sent[MASKW];
   u32 inval[MASKW];
   unsigned short cand[MAXCAND];
+  unsigned short fl[NCHUNK + 4];                         // per chunk: first byte | last byte << 8
   u32 ncand;
 };
 
@@ -121,6 +123,65 @@ __device__ __forceinline__ void classify_word (u32 x, u32 prev_byte, u32 &code8,
   inval4 = (iv | (iv >> 7) | (iv >> 14) | (iv >> 21)) & 0xFu;
   sent4 = gather_bit7 (zero_bytes (x ^ 0x0A0A0A0Au));
   start4 = gather_bit7 (zero_bytes (x ^ ((x << 8) | prev_byte))) ^ 0xFu;   // run start: byte differs from its predecessor
+}
+
+// Fast path of classify_word for the bytes that make up almost all of a read stream: upper-case A C G T and the read
+// delimiter.  Same code / start / delimiter planes (the code of a delimiter byte is never used); `bad` comes back non-zero if some byte is anything else (then the
+// caller redoes the chunk with classify_word, which also produces the non-ACGTU plane).
+__device__ __forceinline__ void classify_word_fast (u32 x, u32 prev_word, u32 &code8, u32 &start4, u32 &sent4, u32 &bad)
+{
+  const u32 c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+  u32 t = c | (c >> 6);
+  code8 = (t | (t >> 12)) & 0xFFu;
+  const u32 expect = __builtin_amdgcn_perm (0u, 0x54474341u, c);      // 'A','C','G','T' indexed by the code
+  u32 zs = zero_bytes (x ^ 0x0A0A0A0Au);                             // 0x80 per delimiter byte
+  bad = (x ^ expect) & ~(zs | (zs - (zs >> 7)));                     // ignore delimiter bytes (0x80 | 0x7f = 0xff)
+  zs >>= 7; t = zs | (zs >> 7);
+  sent4 = (t | (t >> 14)) & 0xFu;
+  u32 ze = zero_bytes (x ^ __builtin_amdgcn_alignbit (x, prev_word, 24)) >> 7;   // byte equals its predecessor
+  t = ze | (ze >> 7);
+  start4 = ((t | (t >> 14)) & 0xFu) ^ 0xFu;
+}
+
+// ---- diagnostic build only (-DTJ_STAMPS=1): where does a tile's time go?  Never enabled in the product library. ----
+#ifndef TJ_STAMPS
+#define TJ_STAMPS 0
+#endif
+#if TJ_STAMPS
+__device__ unsigned long long tj_stamp_acc[32];
+struct Stamper
+{
+  unsigned long long last, acc[16];
+  __device__ __forceinline__ void begin () { for (int i = 0; i < 16; i++) acc[i] = 0; last = __builtin_amdgcn_s_memtime (); }
+  __device__ __forceinline__ void mark (int i) { unsigned long long t = __builtin_amdgcn_s_memtime (); acc[i] += t - last; last = t; }
+  __device__ __forceinline__ void flush () { if (threadIdx.x == 0) for (int i = 0; i < 16; i++) atomicAdd (&tj_stamp_acc[i], acc[i]); }
+};
+#define STAMP_DECL Stamper stamper; stamper.begin (); sink.stp = &stamper
+#define STAMP(i) stamper.mark (i)
+#define PSTAMP(i) stp->mark (i)
+#define STAMP_FLUSH stamper.flush ()
+#define STAMP_MEMBER Stamper *stp;
+extern "C" int tjamd_debug_stamps (unsigned long long *out, int reset)
+{
+  unsigned long long z[32] = {0};
+  if (hipMemcpyFromSymbol (out, HIP_SYMBOL (tj_stamp_acc), 16 * 8) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol (HIP_SYMBOL (tj_stamp_acc), z, 32 * 8) != hipSuccess) return 1;
+  return 0;
+}
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define PSTAMP(i)
+#define STAMP_FLUSH
+#define STAMP_MEMBER
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding global stores and
+// atomics (vmcnt(0), microseconds each under load); inside the scan nothing written to HBM is read back in the same
+// launch, so the bucket writes and the cursor atomics are left in flight across barriers.
+__device__ __forceinline__ void lds_barrier ()
+{
+  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // 64 bits of a little-endian bit array starting at bit position `bitpos` (array padded by >= 2 words)
@@ -231,19 +292,28 @@ __device__ __forceinline__ void emit_record (bool have, u64 c0, u64 c1, u64 meta
 // tile scan, shared by both kernels.  The sink receives, once per round and from every thread of the workgroup
 // (wave- and block-uniform call), at most one tract: (have, ctx0, ctx1, base, 10-bit length, strand flag, position).
 
-__device__ __forceinline__ void load_chunk (const uint8_t *__restrict__ seq, long n_bytes, long g, uint4 &v, u32 &prev)
+// Prefetch of one 16-byte chunk per lane straight into LDS (global_load_lds_dwordx4: no VGPR destination, so nothing
+// the register allocator can turn into a copy that waits for the data).  lds_wave_base is the slot of the wave's first
+// lane; lane l's 16 bytes land at lds_wave_base + l.  A chunk that sticks out of the stream reads the stream's first
+// bytes instead and is rebuilt bytewise when it is consumed.  Requires >= 16 readable bytes at seq (the host pads tiny
+// streams).
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+__device__ __forceinline__ void issue_chunk (const uint8_t *__restrict__ seq, long n_bytes, long g, uint4 *lds_wave_base)
 {
-  if (g >= 0 && g + 16 <= n_bytes) v = *reinterpret_cast<const uint4 *> (seq + g);
-  else {                                                // chunk straddles the ends of the stream (first / last tile only)
-    u64 lo = 0, hi = 0;
-#pragma unroll 1
-    for (int b = 0; b < 8; b++) {
-      lo |= (u64) stream_byte (seq, n_bytes, g + b) << (8 * b);
-      hi |= (u64) stream_byte (seq, n_bytes, g + 8 + b) << (8 * b);
-    }
-    v.x = (u32) lo; v.y = (u32) (lo >> 32); v.z = (u32) hi; v.w = (u32) (hi >> 32);
-  }
-  prev = stream_byte (seq, n_bytes, g - 1);
+  const bool inside = (g >= 0) && (g + 16 <= n_bytes);
+  __builtin_amdgcn_global_load_lds ((gptr_t) (inside ? seq + g : seq), (lptr_t) lds_wave_base, 16, 0, 0);
+}
+
+// the same chunk, byte by byte, for chunks that are not entirely inside the stream (first and last tile only)
+struct EdgeChunk { u32 x, y, z, w; };
+__device__ __noinline__ EdgeChunk edge_chunk (const uint8_t *__restrict__ seq, long n_bytes, long g)
+{
+  u32 w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int b = 0; b < 16; b++) w[b >> 2] |= stream_byte (seq, n_bytes, g + b) << (8 * (b & 3));
+  EdgeChunk e = {w[0], w[1], w[2], w[3]};
+  return e;
 }
 
 template <int BLOCK, int TILE, class Sink>
@@ -255,71 +325,116 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
   const u64 km = kmask (k);
   const u64 kbits = (1ull << k) - 1ull;                 // k <= 32
 
-  uint4 pre[G::NLOAD];
-  u32 pprev[G::NLOAD];
   long tile = blockIdx.x;
+  u32 buf = 0;
   if (tile < n_tiles) {
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
       const int c = tid + i * BLOCK;
-      if (c < G::NCHUNK) load_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, pre[i], pprev[i]);
+      if (c < G::NCHUNK) issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, &T.raw[0][c - (tid & 63)]);
     }
   }
 
+  STAMP_DECL;
   for (; tile < n_tiles; tile += gridDim.x) {
+    STAMP (0);
     const long g0 = tile * (long) TILE - TJ_HL;         // stream position of window byte 0 (may be negative)
 
     // ---- phase 1: classify the prefetched chunks into LDS, then prefetch the next tile ------------------------
     if (tid == 0) T.ncand = 0;
     if (tid < 4) { T.code[G::CODEW - 4 + tid] = 0; T.start[G::MASKW - 4 + tid] = 0; T.sent[G::MASKW - 4 + tid] = 0xFFFFFFFFu; T.inval[G::MASKW - 4 + tid] = 0; }
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's chunks of the tile have landed in T.raw[buf]
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
       const int c = tid + i * BLOCK;
       if (c < G::NCHUNK) {
-        const u32 w[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
-        u32 prev = pprev[i];
-        u32 code32 = 0, st16 = 0, se16 = 0, iv16 = 0;
+        uint4 v = T.raw[buf][c];
+        {
+          const long g = g0 + 16l * c;
+          if (__builtin_expect (!((g >= 0) && (g + 16 <= n_bytes)), 0)) {
+            const EdgeChunk e = edge_chunk (seq, n_bytes, g);
+            v.x = e.x; v.y = e.y; v.z = e.z; v.w = e.w;
+          }
+        }
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+        u32 code32 = 0, st16 = 0, se16 = 0, iv16 = 0, bad = 0;
+        // The byte in front of the chunk belongs to another lane: the chunk's first run-start bit is left 0 here and
+        // patched in phase 2 from the first / last bytes every chunk leaves in T.fl.
+        u32 prevw = w[0] << 24;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          u32 c8, s4, e4, i4;
-          classify_word (w[j], prev, c8, s4, e4, i4);
-          code32 |= c8 << (8 * j); st16 |= s4 << (4 * j); se16 |= e4 << (4 * j); iv16 |= i4 << (4 * j);
-          prev = w[j] >> 24;
+          u32 c8, s4, e4, b;
+          classify_word_fast (w[j], prevw, c8, s4, e4, b);
+          code32 |= c8 << (8 * j); st16 |= s4 << (4 * j); se16 |= e4 << (4 * j); bad |= b;
+          prevw = w[j];
+        }
+        if (__builtin_expect (bad != 0u, 0)) {          // lower case, U, N, anything else: exact classification
+          u32 prev = w[0] & 0xFFu;
+          code32 = st16 = se16 = iv16 = 0;
+          for (int j = 0; j < 4; j++) {
+            u32 c8, s4, e4, i4;
+            classify_word (w[j], prev, c8, s4, e4, i4);
+            code32 |= c8 << (8 * j); st16 |= s4 << (4 * j); se16 |= e4 << (4 * j); iv16 |= i4 << (4 * j);
+            prev = w[j] >> 24;
+          }
         }
         T.code[c] = code32;
         reinterpret_cast<unsigned short *> (T.start)[c] = (unsigned short) st16;
         reinterpret_cast<unsigned short *> (T.sent)[c] = (unsigned short) se16;
-        reinterpret_cast<unsigned short *> (T.inval)[c] = (unsigned short) iv16;
+        reinterpret_cast<unsigned short *> (T.inval)[c] = (unsigned short) (iv16 | se16);
+        T.fl[c] = (unsigned short) ((w[0] & 0xFFu) | ((w[3] >> 24) << 8));
       }
     }
+    sink.tick ();
+    STAMP (1);
     {
       const long nt = tile + gridDim.x;
       if (nt < n_tiles) {
 #pragma unroll
         for (int i = 0; i < G::NLOAD; i++) {
           const int c = tid + i * BLOCK;
-          if (c < G::NCHUNK) load_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, pre[i], pprev[i]);
+          if (c < G::NCHUNK) issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, &T.raw[buf ^ 1u][c - (tid & 63)]);
         }
       }
     }
-    __syncthreads ();
+    STAMP (2);
+    lds_barrier ();
+    STAMP (3);
 
     // ---- phase 2: candidate tract starts among this lane's 16 positions ------------------------------------
     {
-      const int p0 = TJ_HL + 16 * tid;
-      const u64 S = bits64 (T.start, p0);
+      const int p0 = TJ_HL + 16 * tid, c0 = p0 >> 4;
+      u64 S = bits64 (T.start, p0);
+      // first position of a chunk: run start iff its byte differs from the last byte of the chunk before
+      u32 f[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) f[i] = T.fl[c0 - 1 + i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) S |= (u64) ((f[i + 1] & 0xFFu) != (f[i] >> 8)) << (16 * i);
+      if (S & 1ull) reinterpret_cast<unsigned short *> (T.start)[c0] |= 1;          // patch the plane for phase 3
+      if (tid < TJ_HR / 16) {                           // ... and the right halo's chunks, which no lane owns
+        const int ch = (TJ_HL + TILE) / 16 + tid;
+        if ((T.fl[ch] & 0xFFu) != (u32) (T.fl[ch - 1] >> 8)) reinterpret_cast<unsigned short *> (T.start)[ch] |= 1;
+      }
       u32 cand = (u32) S & 0xFFFFu;
       for (int j = 1; j < mprime; j++) cand &= ~(u32) (S >> j);     // next m'-1 positions continue the run
       cand &= ~(u32) reinterpret_cast<unsigned short *> (T.sent)[p0 >> 4];  // a run of delimiters is not a tract
-      if (cand) {
-        u32 at = atomicAdd (&T.ncand, (u32) __popc (cand));
-        while (cand) { int b = __ffs ((int) cand) - 1; cand &= cand - 1u; if (at < (u32) G::MAXCAND) T.cand[at] = (unsigned short) (p0 + b); at++; }
-      }
+      // one LDS atomic per wavefront (512 same-address atomics serialise): exclusive prefix of the lane counts
+      const u32 n = (u32) __popc (cand);
+      u32 incl = n;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up (incl, o); if ((tid & 63) >= o) incl += y; }
+      u32 wbase = 0;
+      if ((tid & 63) == 63 && incl) wbase = atomicAdd (&T.ncand, incl);
+      wbase = __shfl (wbase, 63);
+      u32 at = wbase + incl - n;
+      while (cand) { int b = __ffs ((int) cand) - 1; cand &= cand - 1u; if (at < (u32) G::MAXCAND) T.cand[at] = (unsigned short) (p0 + b); at++; }
     }
-    __syncthreads ();
+    STAMP (4);
+    lds_barrier ();
+    STAMP (5);
 
     // ---- phase 3: one lane per candidate --------------------------------------------------------------------
-    sink.tick ();
     const int ncand = min ((int) T.ncand, G::MAXCAND);
     for (int cb0 = 0; cb0 < ncand; cb0 += BLOCK) {
       const int ci = cb0 + tid;
@@ -371,10 +486,15 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
           }
         }
       }
+      STAMP (6);
       sink.put (have, c0, c1, base, len10, flag, pos);
+      STAMP (7);
     }
-    __syncthreads ();
+    lds_barrier ();
+    buf ^= 1u;
+    STAMP (8);
   }
+  STAMP_FLUSH;
 }
 
 // Non-ACGTU runs that qualify as tracts (reference: src/hopo_counter.c:246-248: add_kmer is called with whatever the
@@ -406,6 +526,7 @@ __device__ bool stale_context (const uint8_t *__restrict__ seq, long n_bytes, lo
 struct ListSink
 {
   u64 *out; u64 cap; DevCounters *ctr;
+  STAMP_MEMBER
   __device__ __forceinline__ void tick () {}
   __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos)
   {
@@ -471,12 +592,14 @@ template <> __device__ __forceinline__ void unpack_raw<4> (const u64 *w, int k, 
 
 // hash of the reduction key (base, context, stored length): bits 0-7 pick the bucket, 8-19 the table slot, 32-63 the tag
 __device__ __forceinline__ u64 hash_key (u64 c0, u64 c1, u32 base, u32 len10)
-{
-  u64 h = (c0 + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
-  h ^= (c1 + 0xD6E8FEB86659FD93ull) * 0x94D049BB133111EBull;
-  h ^= ((u64) (base | (len10 << 2)) + 1ull) * 0xD1B54A32D192ED03ull;
-  h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
-  return h;
+{ // 32-bit arithmetic only (64-bit multiplies cost several quarter-rate instructions each); the tag merely has to
+  // differ from the slot bits: a tag collision costs a key comparison, never a wrong answer
+  u32 a = (u32) c0 ^ __builtin_amdgcn_alignbit ((u32) (c0 >> 32), (u32) (c0 >> 32), 25) ^ __builtin_amdgcn_alignbit ((u32) c1, (u32) c1, 19)
+          ^ __builtin_amdgcn_alignbit ((u32) (c1 >> 32), (u32) (c1 >> 32), 11) ^ ((base | (len10 << 2)) * 0x9E3779B1u);
+  u32 h = a * 0x85EBCA6Bu;
+  h ^= h >> 15; h *= 0xC2B2AE35u; h ^= h >> 16;
+  const u32 tag = (a ^ (a >> 13)) * 0x27D4EB2Fu;
+  return ((u64) tag << 32) | h;
 }
 
 #define TJ_P        256                 // hash buckets
@@ -570,7 +693,8 @@ struct BinLds
   u64 gpos[TJ_P];
   u32 cnt[TJ_P];
   u32 list[TJ_P];
-  u32 nfull, nnull;
+  u32 nfull[2], pend[2];                                // per round parity
+  u32 nnull;
 };
 
 // Thread t < TJ_P owns bin t of its workgroup.  It always holds one block of bucket t reserved in advance (`next`, the
@@ -584,35 +708,43 @@ struct BinSink
   Buckets B; DevCounters *ctr; int k;
   u32 next, cur_j, cur_chunk;                           // owner-thread state (registers)
   bool unclaimed;                                       // `next` was reserved but its chunk-ahead claim is still due
+  u32 round;                                            // insertion rounds so far (workgroup-uniform)
+  STAMP_MEMBER
 
   __device__ __forceinline__ void start ()
   {
     const int tid = threadIdx.x;
     for (int i = tid; i < TJ_P; i += BLOCK) L.cnt[i] = 0;
-    if (tid == 0) { L.nfull = 0; L.nnull = 0; }
-    cur_j = TJ_EMPTY; cur_chunk = 0; next = 0; unclaimed = false;
+    if (tid == 0) { L.nfull[0] = L.nfull[1] = 0; L.pend[0] = L.pend[1] = 0; L.nnull = 0; }
+    cur_j = TJ_EMPTY; cur_chunk = 0; next = 0; unclaimed = false; round = 0;
     if (tid < TJ_P) { next = atomicAdd (&B.cursors[tid], (u32) C); bucket_claim_ahead (B, (u32) tid, next, ctr); }
-    __syncthreads ();
+    lds_barrier ();
   }
 
-  // Once per tile: a reservation made at the last flush has returned by now; if it opened a chunk, claim the next one.
-  // Claims therefore never wait for a bin to fill (other workgroups may already be writing past that chunk).
+  // Once per tile, right after the tile's own loads have been waited for and BEFORE the next tile's loads are issued:
+  // the reservation made at the last flush has returned by now.  Touching it here lets the compiler place its
+  // (in-order) vmcnt wait where nothing is in flight; a first use later in the tile would drain the fresh prefetch.
+  // If the reservation opened a chunk, claim the next one now: claims never wait for a bin to fill.
   __device__ __forceinline__ void tick ()
   {
+    asm volatile ("" : "+v"(next));
     if (unclaimed) { bucket_claim_ahead (B, (u32) threadIdx.x, next, ctr); unclaimed = false; }
   }
 
-  // pool index of the owner's reserved block; reserves the following one
+  // pool index of the owner's reserved block; reserves the following one.  The new reservation is issued LAST, when
+  // the old position is dead, so that its destination can be the loop-carried register itself (a result that has to
+  // be copied into place is waited for on the spot: two microseconds per flush).
   __device__ __forceinline__ u64 take_block (bool reserve_more)
   {
     const int tid = threadIdx.x;
     const u32 p0 = next;
-    tick ();
-    if (reserve_more) { next = atomicAdd (&B.cursors[tid], (u32) C); unclaimed = true; }
+    if (unclaimed) { bucket_claim_ahead (B, (u32) tid, p0, ctr); unclaimed = false; }   // (a second flush within one tile)
     const u32 j = chunk_of_pos (B, p0);
     if (j != cur_j) { cur_j = j; cur_chunk = bucket_chunk_id (B, (u32) tid, j, true, ctr); }   // first block here: look the chunk up
-    if (cur_chunk >= TJ_NOCHUNK) return ~0ull;
-    return (((u64) cur_chunk * TJ_CH0) << B.ch_shift) + (p0 - ((j * TJ_CH0) << B.ch_shift));
+    u64 g = ~0ull;
+    if (cur_chunk < TJ_NOCHUNK) g = (((u64) cur_chunk * TJ_CH0) << B.ch_shift) + (p0 - ((j * TJ_CH0) << B.ch_shift));
+    if (reserve_more) { next = atomicAdd (&B.cursors[tid], (u32) C); unclaimed = true; }
+    return g;
   }
 
   __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos)
@@ -623,6 +755,8 @@ struct BinSink
     if (have) { pack_raw<W> (c0, c1, base, len10, flag, k, w); b = (u32) hash_key (c0, c1, base, len10) & (TJ_P - 1); }
     bool pending = have;
     for (;;) {
+      const u32 par = round & 1u;
+      round++;
       if (pending) {
         const u32 s = atomicAdd (&L.cnt[b], 1u);
         if (s < (u32) C) {
@@ -631,27 +765,44 @@ struct BinSink
           for (int j = 0; j < W; j++) q[j] = w[j];
           pending = false;
         }
+        else L.pend[par] = 1u;                          // bin full: again after the flush
       }
-      const int anyp = __syncthreads_or (pending ? 1 : 0);
-      const bool full = (tid < TJ_P) && (L.cnt[tid] >= (u32) C);
-      const int nfull = __syncthreads_count (full ? 1 : 0);
-      if (nfull) {                                      // every full bin goes out as one 128-byte line of its bucket
-        if (full) {
-          L.list[atomicAdd (&L.nfull, 1u)] = (u32) tid;
-          L.gpos[tid] = take_block (true);
-          L.cnt[tid] = 0;
+      PSTAMP (9);
+      lds_barrier ();                                   // (1) every insert of the round is in LDS
+      PSTAMP (10);
+      if (tid == 0) { L.nfull[par ^ 1u] = 0; L.pend[par ^ 1u] = 0; }
+      {                                                 // every full bin goes out as one 128-byte line of its bucket
+        const bool full = (tid < TJ_P) && (L.cnt[tid] >= (u32) C);
+        const u64 fm = __ballot (full);
+        if (fm) {                                       // one LDS atomic per wavefront for the list position
+          const int lane = tid & 63, leader = __ffsll ((long long) fm) - 1;
+          u32 lb = 0;
+          if (lane == leader) lb = atomicAdd (&L.nfull[par], (u32) __popcll (fm));
+          lb = __shfl (lb, leader);
+          if (full) {
+            L.list[lb + (u32) __popcll (fm & ((1ull << lane) - 1ull))] = (u32) tid;
+            L.gpos[tid] = take_block (true);
+            L.cnt[tid] = 0;
+          }
         }
-        __syncthreads ();
-        for (int i = tid; i < nfull * TJ_BINWORDS; i += BLOCK) {
-          const u32 bin = L.list[i / TJ_BINWORDS];
-          const int wj = i % TJ_BINWORDS;
-          const u64 g = L.gpos[bin];
-          if (g != ~0ull) B.pool[g * W + wj] = L.bins[bin * TJ_BINWORDS + wj];
-        }
-        __syncthreads ();
-        if (tid == 0) L.nfull = 0;
       }
-      if (!anyp) break;
+      PSTAMP (11);
+      lds_barrier ();                                   // (2) list of full bins complete
+      PSTAMP (12);
+      const int nfull = (int) L.nfull[par];
+      const bool again = L.pend[par] != 0u;
+      for (int i = tid; i < nfull * TJ_BINWORDS; i += BLOCK) {
+        const u32 bin = L.list[i / TJ_BINWORDS];
+        const int wj = i % TJ_BINWORDS;
+        const u64 g = L.gpos[bin];
+#ifndef TJ_EXP_NOSTORE
+        if (g != ~0ull) B.pool[g * W + wj] = L.bins[bin * TJ_BINWORDS + wj];
+#endif
+      }
+      PSTAMP (13);
+      lds_barrier ();                                   // (3) the copied bins may be refilled from here on
+      PSTAMP (14);
+      if (!again) break;
     }
   }
 
@@ -659,7 +810,7 @@ struct BinSink
   { // the reserved block of every bin takes what is left in the bin, padded with null records
     const int tid = threadIdx.x;
     tick ();
-    __syncthreads ();
+    lds_barrier ();
     if (tid < TJ_P) {
       const u32 n = min (L.cnt[tid], (u32) C);
       const u64 g = take_block (false);
@@ -672,23 +823,23 @@ struct BinSink
         atomicAdd (&L.nnull, (u32) C - n);
       }
     }
-    __syncthreads ();
+    lds_barrier ();
     if (tid == 0 && L.nnull) atomicAdd (&ctr->n_null, (u64) L.nnull);
   }
 };
 
 #define TJ_SB_BLOCK 512
 #define TJ_SB_TILE  8192
-#define TJ_SB_WG_PER_CU 3               // ~50 KB of LDS and <= 80 VGPRs per workgroup
+#define TJ_SB_WG_PER_CU 3               // ~50 KB of LDS per workgroup (registers may allow only 2: the third then queues)
 
 template <int W>
-__global__ __launch_bounds__ (TJ_SB_BLOCK, 6)
+__global__ __launch_bounds__ (TJ_SB_BLOCK)
 void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
                        Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
 {
   __shared__ TileLds<TJ_SB_BLOCK, TJ_SB_TILE> T;
   __shared__ BinLds<W> B;
-  BinSink<W, TJ_SB_BLOCK> sink = {B, BK, ctr, k, 0u, 0u, 0u, false};
+  BinSink<W, TJ_SB_BLOCK> sink = {B, BK, ctr, k, 0u, 0u, 0u, false, 0u};
   sink.start ();
   scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE> (seq, n_bytes, n_tiles, k, mprime, T, sink, ctr, fix, fix_cap);
   sink.finish ();
@@ -1397,6 +1548,12 @@ extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t
   if (n_bytes == 0) return TJAMD_OK;
   if (!d_stream || ((uintptr_t) d_stream & 15u)) return set_err (TJAMD_ERR_ARG, "device stream pointer must be non-null and 16-byte aligned");
   HIPCHK (hipSetDevice (c->device));
+  if (n_bytes < 64 && d_stream != c->stage.p) {             // the kernels read whole 16-byte chunks: give tiny streams room
+    rc = ensure (c->stage, 256, c->stream);
+    if (rc) return rc;
+    HIPCHK (hipMemcpyAsync (c->stage.p, d_stream, n_bytes, hipMemcpyDeviceToDevice, c->stream));
+    d_stream = c->stage.p;
+  }
   const int mprime = std::max (min_tract_size, 2);          // a tract needs two equal bytes: m = 1 behaves as m = 2
   // tracts are disjoint runs of >= m' bytes: at most n/m' records come out of this batch
   const u64 bound = (u64) ((double) (n_bytes / (size_t) mprime + 1) * c->slack);

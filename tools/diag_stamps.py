@@ -1,0 +1,39 @@
+"""Diagnostic only: per-phase time shares of the scan kernel from in-kernel s_memtime stamps.
+Needs tatajuba_amd/libtatajuba_amd_diag.so (hopo_device.hip built with -DTJ_STAMPS=1; see tools/build_diag.sh).
+The stamped build's run time is not a benchmark number (its stamps serialise the phases); read the shares."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tatajuba_amd.build as B
+B._SO = os.path.join(ROOT, "tatajuba_amd", os.environ.get("TJ_DIAG_LIB", "libtatajuba_amd_diag.so"))
+import tatajuba_amd.capi as capi
+capi.library_path = lambda: B._SO
+import tatajuba_amd as tj
+import torch
+
+L = tj.lib()
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+s = tj.synth_stream(n_reads, 150, 5_000_000, n_threads=16)
+d = torch.from_numpy(s).cuda()
+c = tj.Counter(10)
+out = (C.c_ulonglong * 16)()
+for it in range(3):
+    c.reset()
+    c.scan_device(d.data_ptr(), s.size, 3)
+    c.sync()
+    L.tjamd_debug_stamps(out, 1)
+v = np.array(list(out), dtype=np.float64)
+names = ["loop-top", "classify", "prefetch-issue", "barrierA", "phase2", "barrierB", "phase3-compute", "put",
+         "barrier-end"]
+print("stamped scan ms", c.last_scan_ms())
+tot = v[:9].sum()
+for n, x in zip(names, v[:9]):
+    print(f"{n:16s} {x / tot * 100:6.2f} %")
+pn = ["put:insert", "put:barrier1", "put:owners(take_block)", "put:barrier2", "put:copy", "put:barrier3"]
+for n, x in zip(pn, v[9:15]):
+    print(f"   {n:24s} {x / tot * 100:6.2f} %   (inside put)")
