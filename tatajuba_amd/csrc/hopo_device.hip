@@ -72,7 +72,8 @@ struct TileLds
   static constexpr int CODEW = WIN / 16 + 4;             // words of 2-bit codes (+ pad)
   static constexpr int MAXCAND = TILE / 2;               // tracts have >= 2 bases: at most one candidate per 2 bytes
   static constexpr int NLOAD = (NCHUNK + BLOCK - 1) / BLOCK;
-  uint4 raw[2][NCHUNK];                                  // next tile's bytes land here straight from HBM (LDS-DMA)
+  uint4 raw[NCHUNK];                                     // next tile's bytes land here straight from HBM (LDS-DMA);
+                                                         // slot c is read and refilled only by the lane that owns chunk c
   u32 code[CODEW];
   u32 start[MASKW];
   u32 sent[MASKW];
@@ -326,12 +327,11 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
   const u64 kbits = (1ull << k) - 1ull;                 // k <= 32
 
   long tile = blockIdx.x;
-  u32 buf = 0;
   if (tile < n_tiles) {
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
       const int c = tid + i * BLOCK;
-      if (c < G::NCHUNK) issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, &T.raw[0][c - (tid & 63)]);
+      if (c < G::NCHUNK) issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, &T.raw[c - (tid & 63)]);
     }
   }
 
@@ -343,12 +343,12 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     // ---- phase 1: classify the prefetched chunks into LDS, then prefetch the next tile ------------------------
     if (tid == 0) T.ncand = 0;
     if (tid < 4) { T.code[G::CODEW - 4 + tid] = 0; T.start[G::MASKW - 4 + tid] = 0; T.sent[G::MASKW - 4 + tid] = 0xFFFFFFFFu; T.inval[G::MASKW - 4 + tid] = 0; }
-    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's chunks of the tile have landed in T.raw[buf]
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's chunks of the tile have landed in T.raw
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
       const int c = tid + i * BLOCK;
       if (c < G::NCHUNK) {
-        uint4 v = T.raw[buf][c];
+        uint4 v = T.raw[c];
         {
           const long g = g0 + 16l * c;
           if (__builtin_expect (!((g >= 0) && (g + 16 <= n_bytes)), 0)) {
@@ -393,7 +393,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
 #pragma unroll
         for (int i = 0; i < G::NLOAD; i++) {
           const int c = tid + i * BLOCK;
-          if (c < G::NCHUNK) issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, &T.raw[buf ^ 1u][c - (tid & 63)]);
+          if (c < G::NCHUNK) issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, &T.raw[c - (tid & 63)]);
         }
       }
     }
@@ -491,7 +491,6 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
       STAMP (7);
     }
     lds_barrier ();
-    buf ^= 1u;
     STAMP (8);
   }
   STAMP_FLUSH;
@@ -781,8 +780,8 @@ struct BinSink
           lb = __shfl (lb, leader);
           if (full) {
             L.list[lb + (u32) __popcll (fm & ((1ull << lane) - 1ull))] = (u32) tid;
+            L.cnt[tid] = 0;                              // (before take_block: see the note there about waits)
             L.gpos[tid] = take_block (true);
-            L.cnt[tid] = 0;
           }
         }
       }
