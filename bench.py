@@ -76,8 +76,9 @@ def main():
         if st != 0:
             raise SystemExit(f"finalise status {st}")
         if world > 1:                                     # exchange step: all-gatherv of the per-sample histograms
-            from tatajuba_amd.dist import all_gather_histograms
-            gathered = all_gather_histograms(c, dist)
+            from tatajuba_amd.dist import all_gather_histograms, merge_histograms_device
+            rec, cnts = all_gather_histograms(c, dist)
+            gathered = merge_histograms_device(c, rec, cnts)    # every rank holds the merged union (reference: genome_set.c:250-289)
         return c.last_scan_ms(), c.last_finalise_ms()
 
     def fence():

@@ -1297,6 +1297,44 @@ void cov_max_kernel (const u32 *__restrict__ keys, const int *__restrict__ sums,
 
 __global__ void set_int_kernel (int *p, int v) { *p = v; }
 
+// ---- cross-sample merge (context-keyed union of the samples' histograms; reference precursor: src/genome_set.c:250-289)
+#define TJ_META_SAMPLE_SHIFT 52          // bits 52..63 of the bitfield word are unused by hopo_element
+
+__global__ void merge_tag_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, long n, const long *__restrict__ starts, int n_samples)
+{ // copy + write the sample index of every record into the spare bits of its meta word
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_samples;                         // starts[s] <= i < starts[s + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= i) lo = mid; else hi = mid; }
+    out[3 * i] = in[3 * i]; out[3 * i + 1] = in[3 * i + 1];
+    out[3 * i + 2] = (in[3 * i + 2] & ((1ull << TJ_META_SAMPLE_SHIFT) - 1ull)) | ((u64) lo << TJ_META_SAMPLE_SHIFT);
+  }
+}
+
+__global__ void merge_write_kernel (const u64 *__restrict__ rec, long n, const u32 *__restrict__ flags, const u32 *__restrict__ segid,
+                                    int n_samples, u64 *__restrict__ keys, int *__restrict__ counts, u32 *__restrict__ totals, long cap)
+{
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
+    const u32 seg = segid[i] + flags[i] - 1u;           // exclusive scan of the head flags: heads before i (+ itself) - 1
+    if ((long) seg >= cap) continue;
+    const u64 meta = rec[3 * i + 2];
+    const int sample = (int) (meta >> TJ_META_SAMPLE_SHIFT);
+    const int cnt = meta_count (meta);
+    counts[(long) seg * n_samples + sample] = cnt;
+    atomicAdd (&totals[seg], (u32) cnt);
+    if (flags[i]) { keys[3 * (long) seg] = rec[3 * i]; keys[3 * (long) seg + 1] = rec[3 * i + 1]; keys[3 * (long) seg + 2] = meta; }
+  }
+}
+
+__global__ void merge_totals_kernel (u64 *__restrict__ keys, const u32 *__restrict__ totals, const u32 *n_seg_p, long cap)
+{ // count field := depth over all samples (20-bit store), canon_flag as in the first sample that has the key
+  const long n_seg = min ((long) *n_seg_p, cap);
+  for (long j = blockIdx.x * (long) blockDim.x + threadIdx.x; j < n_seg; j += (long) gridDim.x * blockDim.x) {
+    u64 m = keys[3 * j + 2] & ((1ull << TJ_META_SAMPLE_SHIFT) - 1ull);
+    m = (m & ~(0xFFFFFull << TJ_META_COUNT_SHIFT)) | (((u64) totals[j] & 0xFFFFFull) << TJ_META_COUNT_SHIFT);
+    keys[3 * j + 2] = m;
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side of the thin layer
@@ -1903,6 +1941,43 @@ extern "C" long tjamd_last_scan_launches (tjamd_counter *c) { return c ? c->last
 extern "C" long tjamd_merge_samples (tjamd_counter *c, const void *d_records, const long *counts, int n_samples,
                                       void *d_out_keys, void *d_out_counts, long capacity)
 {
-  (void) c; (void) d_records; (void) counts; (void) n_samples; (void) d_out_keys; (void) d_out_counts; (void) capacity;
-  return -set_err (TJAMD_ERR_STATE, "tjamd_merge_samples: not built yet");
+  if (!c || !counts || n_samples < 1 || n_samples > 4096 || !d_out_keys || !d_out_counts) return -set_err (TJAMD_ERR_ARG, "bad arguments");
+  if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
+  std::vector<long> starts ((size_t) n_samples + 1);
+  long n = 0;
+  for (int i = 0; i < n_samples; i++) { if (counts[i] < 0) return -set_err (TJAMD_ERR_ARG, "negative count"); starts[i] = n; n += counts[i]; }
+  starts[n_samples] = n;
+  if (n == 0) return 0;
+  if (!d_records) return -set_err (TJAMD_ERR_ARG, "null records");
+  int rc = ensure (c->prefix, (size_t) (n_samples + 1) * 8, c->stream);
+  if (!rc) rc = ensure (c->rawlist, (size_t) n * 24, c->stream);
+  if (!rc) rc = ensure (c->alt, (size_t) n * 24, c->stream);
+  if (!rc) rc = ensure (c->flags, (size_t) n * 4, c->stream);
+  if (!rc) rc = ensure (c->segid, (size_t) n * 4, c->stream);
+  if (!rc) rc = ensure (c->keep, (size_t) n * 4, c->stream);          // totals per union key
+  if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n) * 4, c->stream);
+  if (rc) return -rc;
+  if (hipMemcpyAsync (c->prefix.p, starts.data (), (size_t) (n_samples + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  hipLaunchKernelGGL (merge_tag_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) d_records, (u64 *) c->rawlist.p, n, (const long *) c->prefix.p, n_samples);
+  u64 *a = (u64 *) c->rawlist.p, *b = (u64 *) c->alt.p;
+  rc = radix_sort_records (c, a, b, n);               // the reference's order; the sample tag does not take part
+  if (rc) return -rc;
+  if (a != (u64 *) c->rawlist.p) std::swap (c->rawlist, c->alt);
+  u32 *flags = (u32 *) c->flags.p, *segid = (u32 *) c->segid.p;
+  hipLaunchKernelGGL (seg_heads_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) a, n, flags, 0);
+  rc = exclusive_scan (c, flags, segid, n, &c->d_fin->n_seg, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
+  if (rc) return -rc;
+  if (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "merge failed: %s", hipGetErrorString (hipGetLastError ()));
+  const long n_union = c->h_fin->n_seg;
+  if (n_union > capacity) return -set_err (TJAMD_ERR_CAPACITY, "%ld union keys, caller capacity %ld", n_union, capacity);
+  if (hipMemsetAsync (d_out_counts, 0, (size_t) n_union * n_samples * 4, c->stream) != hipSuccess ||
+      hipMemsetAsync (c->keep.p, 0, (size_t) n_union * 4, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "memset failed");
+  hipLaunchKernelGGL (merge_write_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) a, n, (const u32 *) flags, (const u32 *) segid,
+                      n_samples, (u64 *) d_out_keys, (int *) d_out_counts, (u32 *) c->keep.p, capacity);
+  hipLaunchKernelGGL (merge_totals_kernel, dim3 (grid_for (n_union)), dim3 (256), 0, c->stream, (u64 *) d_out_keys, (const u32 *) c->keep.p,
+                      (const u32 *) &c->d_fin->n_seg, capacity);
+  if (hipGetLastError () != hipSuccess || hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "merge kernels failed");
+  return n_union;
 }

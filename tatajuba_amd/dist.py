@@ -45,6 +45,25 @@ def all_gather_histograms(counter, dist, group=None):
     return torch.cat(parts), [s // RECORD_BYTES for s in sizes]
 
 
+def merge_histograms_device(counter, records_u8, counts):
+    """Context-keyed union on the GPU (tjamd_merge_samples): records_u8 = CUDA uint8 tensor holding the samples' kept
+    records back to back, counts = records per sample.  Returns (keys uint8 tensor [n_union*24], int32 tensor
+    [n_union, n_samples]) in the reference's descending key order."""
+    import ctypes as C
+    from .capi import lib, TatajubaAmdError, _err
+    n = int(sum(counts))
+    ns = len(counts)
+    keys = torch.empty(max(n, 1) * RECORD_BYTES, dtype=torch.uint8, device=records_u8.device)
+    mat = torch.empty((max(n, 1), ns), dtype=torch.int32, device=records_u8.device)
+    arr = (C.c_long * ns)(*[int(x) for x in counts])
+    torch.cuda.current_stream().synchronize()
+    got = lib().tjamd_merge_samples(counter._h, C.c_void_p(records_u8.data_ptr()), arr, ns, C.c_void_p(keys.data_ptr()),
+                                    C.c_void_p(mat.data_ptr()), n)
+    if got < 0:
+        raise TatajubaAmdError(_err())
+    return keys[: got * RECORD_BYTES], mat[:got]
+
+
 def merge_histograms_host(records_u8, counts):
     """Context-keyed union of the samples' histograms on the host (numpy; small: 1e5-1e6 records per sample).
     Key = (base, ctx0, ctx1, length) in the reference's descending order; returns (keys structured array, int32 matrix

@@ -1,0 +1,87 @@
+"""The N > 1 path on CPU: two gloo ranks, one sample each, all-gatherv of the per-sample histograms and the
+context-keyed merge (tatajuba_amd/dist.py).  The histograms come from the CPU oracle here (no GPU in this test); the
+GPU version of the same exchange runs in bench.py --gpus N and in tests/test_gpu_parity.py::test_merge_samples_device."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import tatajuba_amd as tj
+from oracle import orc
+from tatajuba_amd.dist import all_gatherv_bytes, merge_histograms_host, RECORD_BYTES
+
+
+def _sample_records(rank):
+    s = tj.synth_stream(4000 + 500 * rank, 150, 60000, seed_reads=0x7A7A1000 + rank, variant_seed=rank, n_threads=1)
+    o = orc.Oracle(10)
+    o.scan_stream(s, 3)
+    o.finalise(1, 0)
+    e = o.elems()
+    r = np.zeros(len(e), dtype=tj.RECORD_DTYPE)
+    for f in ("ctx0", "ctx1", "meta"):
+        r[f] = e[f]
+    return r
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = _sample_records(rank)
+    local = torch.from_numpy(mine.view(np.uint8).copy())
+    parts, sizes = all_gatherv_bytes(local, dist)
+    assert sizes[rank] == mine.nbytes and all(s % RECORD_BYTES == 0 for s in sizes)
+    allrec = torch.cat(parts).numpy()
+    counts = [s // RECORD_BYTES for s in sizes]
+    keys, mat = merge_histograms_host(allrec, counts)
+    # every rank computes the same union
+    digest = torch.tensor([int(mat.astype(np.int64).sum()), len(keys)], dtype=torch.int64)
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
+    if rank == 0:
+        q.put((counts, len(keys), mat.sum(axis=0).tolist(), (mat > 0).sum(axis=1).max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_and_merge():
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    counts, n_union, colsum, max_share = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    recs = [_sample_records(r) for r in range(2)]
+    assert counts == [len(r) for r in recs]
+    for r, tot in zip(recs, colsum):
+        assert int(tj.decode_meta(r["meta"])["count"].sum()) == tot          # every depth lands in its sample's column
+    allkeys = set()
+    for r in recs:
+        d = tj.decode_meta(r["meta"])
+        allkeys |= set(zip(d["base"].tolist(), r["ctx0"].tolist(), r["ctx1"].tolist(), d["length"].tolist()))
+    assert n_union == len(allkeys) and max_share == 2                         # the two samples share tracts
+
+
+def test_merge_host_order_and_counts():
+    a, b = _sample_records(0), _sample_records(1)
+    rec = np.concatenate([a, b]).view(np.uint8)
+    keys, mat = merge_histograms_host(rec, [len(a), len(b)])
+    k = np.stack([keys["base"].astype(np.int64), keys["ctx0"].astype(np.int64), keys["ctx1"].astype(np.int64)], 1)
+    tup = list(zip(keys["base"].tolist(), keys["ctx0"].tolist(), keys["ctx1"].tolist(), keys["length"].tolist()))
+    assert all(tup[i] > tup[i + 1] for i in range(len(tup) - 1))              # reference's descending order, no duplicates
+    da = tj.decode_meta(a["meta"])
+    first = (int(da["base"][0]), int(a["ctx0"][0]), int(a["ctx1"][0]), int(da["length"][0]))
+    assert mat[tup.index(first), 0] == da["count"][0]
+    assert mat.shape == (len(tup), 2) and (mat >= 0).all() and (mat.sum(axis=1) > 0).all()

@@ -328,6 +328,33 @@ def test_dropin_large_file_batches(tmp_path):
     h.delete()
 
 
+def test_merge_samples_device():
+    """cross-sample merge on the GPU == the numpy union (tatajuba_amd/dist.py), counts per sample and key order"""
+    torch = pytest.importorskip("torch")
+    from tatajuba_amd.dist import merge_histograms_device, merge_histograms_host, device_bytes_tensor
+    parts, counts, counters = [], [], []
+    for smp in range(3):
+        s = tj.synth_stream(30000, 150, 200000, seed_reads=0x7A7A1000 + smp, variant_seed=smp)
+        c = tj.Counter(15)
+        c.scan_host(s, 4)
+        assert c.finalise(1, 0) == 0
+        counters.append(c)
+        counts.append(c.n_kept)
+        parts.append(device_bytes_tensor(c.kept_device_ptr, c.n_kept * 24, torch.device("cuda", 0)).clone())
+    rec = torch.cat(parts)
+    keys_d, mat_d = merge_histograms_device(counters[0], rec, counts)
+    keys_h, mat_h = merge_histograms_host(rec.cpu().numpy(), counts)
+    kd = np.frombuffer(keys_d.cpu().numpy().tobytes(), dtype=tj.RECORD_DTYPE)
+    dd = tj.decode_meta(kd["meta"])
+    assert len(kd) == len(keys_h)
+    assert (kd["ctx0"] == keys_h["ctx0"]).all() and (kd["ctx1"] == keys_h["ctx1"]).all()
+    assert (dd["base"] == keys_h["base"]).all() and (dd["length"] == keys_h["length"]).all()
+    assert (mat_d.cpu().numpy() == mat_h).all()
+    assert (dd["count"] == mat_h.sum(axis=1)).all()
+    for c in counters:
+        c.close()
+
+
 # ---- full benchmark size: size-independent properties ---------------------------------------------------------------
 
 def _revcomp_stream(s, L):
