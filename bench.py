@@ -116,16 +116,28 @@ def main():
     # (SURVEY 8d quotes L + 8 for an offsets-table layout; the sentinel layout carries boundaries in-band -- DESIGN.md)
     scan_bytes = float(n_bytes)
     scan_gbs = scan_bytes / (scan_avg * 1e-3) / 1e9
-    # sort+reduce stage: one-pass bound read 24 B per raw record, write 24 B per kept record
-    fin_bytes = 24.0 * raw + 24.0 * kept
+    # sort+reduce stage, one-pass bound: read every raw record once (8*W bytes in this layout), write 24 B
+    # per kept record
+    wbytes = 8.0 * (1 if k <= 12 else (2 if k <= 28 else 4))
+    fin_bytes = wbytes * raw + 24.0 * kept
     fin_gbs = fin_bytes / (fin_avg * 1e-3) / 1e9
     dominant = "scan" if scan_avg >= fin_avg else "finalise"
+    # HBM bytes per launch from the PMC passes of the same command (tools/pmc_traffic.py -> profiles/; rocprofv3 cannot
+    # run inside the timed process), only when they were taken on this workload
+    traffic = {}
+    try:
+        tj_prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        if args.reads == 10_000_000 and L == 150 and k == 10 and m == 3:
+            traffic = {kk: vv["hbm_bytes"] for kk, vv in tj_prof.items() if isinstance(vv, dict)}
+    except (OSError, ValueError, KeyError):
+        pass
     roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None}
     if dominant == "scan":
-        roof.update({"kernel": "scan_kernel<3>", "achieved": scan_gbs, "frac": scan_gbs / HBM_PEAK_GBS,
-                     "ms": scan_avg, "algorithmic_bytes": scan_bytes})
+        roof.update({"kernel": "scan_bins_kernel<1>" if k <= 12 else ("scan_bins_kernel<2>" if k <= 28 else "scan_bins_kernel<4>"),
+                     "achieved": scan_gbs, "frac": scan_gbs / HBM_PEAK_GBS, "ms": scan_avg, "algorithmic_bytes": scan_bytes,
+                     "traffic": traffic.get("scan_bins_kernel<1>") if k <= 12 else None})
     else:
-        roof.update({"kernel": "finalise (radix_scatter_kernel dominates)", "achieved": fin_gbs, "frac": fin_gbs / HBM_PEAK_GBS,
+        roof.update({"kernel": "finalise (aggregate_kernel dominates)", "achieved": fin_gbs, "frac": fin_gbs / HBM_PEAK_GBS,
                      "ms": fin_avg, "algorithmic_bytes": fin_bytes})
 
     out = {
