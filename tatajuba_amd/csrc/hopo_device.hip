@@ -72,8 +72,6 @@ struct TileLds
   static constexpr int CODEW = WIN / 16 + 4;             // words of 2-bit codes (+ pad)
   static constexpr int MAXCAND = TILE / 2;               // tracts have >= 2 bases: at most one candidate per 2 bytes
   static constexpr int NLOAD = (NCHUNK + BLOCK - 1) / BLOCK;
-  uint4 raw[NCHUNK];                                     // next tile's bytes land here straight from HBM (LDS-DMA);
-                                                         // slot c is read and refilled only by the lane that owns chunk c
   u32 code[CODEW];
   u32 start[MASKW];
   u32 sent[MASKW];
@@ -317,9 +315,13 @@ __device__ __noinline__ EdgeChunk edge_chunk (const uint8_t *__restrict__ seq, l
   return e;
 }
 
+// `raw` is the LDS-DMA landing zone: next tile's bytes arrive there straight from HBM; slot c is read and refilled only
+// by the lane that owns chunk c.  It must be a __shared__ variable of its own: the compiler orders every later LDS access
+// that MAY alias an in-flight LDS-DMA behind vmcnt(0), and members of one struct all may alias -- as part of TileLds the
+// "prefetch" was waited for at the first LDS instruction after its issue.
 template <int BLOCK, int TILE, class Sink>
 __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
-                                            TileLds<BLOCK, TILE> &T, Sink &sink, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
+                                            TileLds<BLOCK, TILE> &T, uint4 *raw, Sink &sink, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
 {
   typedef TileLds<BLOCK, TILE> G;
   const int tid = threadIdx.x;
@@ -331,7 +333,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
       const int c = tid + i * BLOCK;
-      if (c < G::NCHUNK) issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, &T.raw[c - (tid & 63)]);
+      if (c < G::NCHUNK) issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, &raw[c - (tid & 63)]);
     }
   }
 
@@ -343,12 +345,12 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     // ---- phase 1: classify the prefetched chunks into LDS, then prefetch the next tile ------------------------
     if (tid == 0) T.ncand = 0;
     if (tid < 4) { T.code[G::CODEW - 4 + tid] = 0; T.start[G::MASKW - 4 + tid] = 0; T.sent[G::MASKW - 4 + tid] = 0xFFFFFFFFu; T.inval[G::MASKW - 4 + tid] = 0; }
-    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's chunks of the tile have landed in T.raw
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's chunks of the tile have landed in raw
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
       const int c = tid + i * BLOCK;
       if (c < G::NCHUNK) {
-        uint4 v = T.raw[c];
+        uint4 v = raw[c];
         {
           const long g = g0 + 16l * c;
           if (__builtin_expect (!((g >= 0) && (g + 16 <= n_bytes)), 0)) {
@@ -393,13 +395,16 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
 #pragma unroll
         for (int i = 0; i < G::NLOAD; i++) {
           const int c = tid + i * BLOCK;
-          if (c < G::NCHUNK) issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, &T.raw[c - (tid & 63)]);
+          if (c < G::NCHUNK) issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, &raw[c - (tid & 63)]);
         }
       }
     }
     STAMP (2);
     lds_barrier ();
     STAMP (3);
+#if defined(TJ_EXP_STOP_AFTER) && TJ_EXP_STOP_AFTER == 1
+    continue;
+#endif
 
     // ---- phase 2: candidate tract starts among this lane's 16 positions ------------------------------------
     {
@@ -433,6 +438,9 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     STAMP (4);
     lds_barrier ();
     STAMP (5);
+#if defined(TJ_EXP_STOP_AFTER) && TJ_EXP_STOP_AFTER == 2
+    continue;
+#endif
 
     // ---- phase 3: one lane per candidate --------------------------------------------------------------------
     const int ncand = min ((int) T.ncand, G::MAXCAND);
@@ -487,7 +495,11 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
         }
       }
       STAMP (6);
+#if defined(TJ_EXP_STOP_AFTER) && TJ_EXP_STOP_AFTER == 3
+      if (have) asm volatile ("" :: "v"(c0), "v"(c1), "v"(base), "v"(len10), "v"(flag), "v"(pos));
+#else
       sink.put (have, c0, c1, base, len10, flag, pos);
+#endif
       STAMP (7);
     }
     lds_barrier ();
@@ -538,8 +550,9 @@ void scan_list_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
                        u64 *__restrict__ out, u64 cap, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
 {
   __shared__ TileLds<256, 4096> T;
+  __shared__ uint4 raw[TileLds<256, 4096>::NCHUNK];
   ListSink sink = {out, cap, ctr};
-  scan_tiles<256, 4096> (seq, n_bytes, n_tiles, k, mprime, T, sink, ctr, fix, fix_cap);
+  scan_tiles<256, 4096> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap);
 }
 
 __global__ void nrun_fixup_list_kernel (const uint8_t *__restrict__ seq, long n_bytes, int k, int mprime,
@@ -837,10 +850,11 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
                        Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
 {
   __shared__ TileLds<TJ_SB_BLOCK, TJ_SB_TILE> T;
+  __shared__ uint4 raw[TileLds<TJ_SB_BLOCK, TJ_SB_TILE>::NCHUNK];
   __shared__ BinLds<W> B;
   BinSink<W, TJ_SB_BLOCK> sink = {B, BK, ctr, k, 0u, 0u, 0u, false, 0u};
   sink.start ();
-  scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE> (seq, n_bytes, n_tiles, k, mprime, T, sink, ctr, fix, fix_cap);
+  scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap);
   sink.finish ();
 }
 
