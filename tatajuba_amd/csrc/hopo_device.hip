@@ -498,7 +498,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
 #if defined(TJ_EXP_STOP_AFTER) && TJ_EXP_STOP_AFTER == 3
       if (have) asm volatile ("" :: "v"(c0), "v"(c1), "v"(base), "v"(len10), "v"(flag), "v"(pos));
 #else
-      sink.put (have, c0, c1, base, len10, flag, pos);
+      sink.put (have, c0, c1, base, len10, flag, pos, (u32) min (ncand - cb0, BLOCK));
 #endif
       STAMP (7);
     }
@@ -539,7 +539,7 @@ struct ListSink
   u64 *out; u64 cap; DevCounters *ctr;
   STAMP_MEMBER
   __device__ __forceinline__ void tick () {}
-  __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos)
+  __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos, u32 round_max)
   {
     emit_record<4> (have, c0, c1, make_meta (base, len10, flag), pos, out, cap, ctr);
   }
@@ -616,16 +616,16 @@ __device__ __forceinline__ u64 hash_key (u64 c0, u64 c1, u32 base, u32 len10)
 
 #define TJ_P        256                 // hash buckets
 #define TJ_PBITS    8
-#define TJ_BINWORDS 16                  // 64-bit words per LDS write-combining bin: one 128-byte line
-#define TJ_CH0      1536                // chunk size unit in records (multiple of every bin's record count 16 / 8 / 4)
+#define TJ_STAGE_WORDS 4096             // 64-bit words of records a workgroup stages in LDS between partition passes
+#define TJ_CH0      1536                // chunk size unit in records; chunks are TJ_CH0 << ch_shift with ch_shift >= 2
 #define TJ_EMPTY    0xFFFFFFFFu
 
-// Bucket storage.  A bucket is a sequence of records numbered by its cursor, handed out in blocks of one bin (C
-// records = 128 bytes, so a block never straddles anything); record `pos` lives in the bucket's (pos / CH)-th chunk.
-// Chunks come from one pool: chunk 0 of every bucket is assigned by the host, and the thread that reserves the FIRST
-// block of chunk j takes chunk j + 1 from the pool and publishes it in the bucket's table -- a whole chunk before anybody
-// needs it, so nobody waits in practice, nothing leaks, and a skewed hash distribution costs nothing: memory follows
-// the data, not the fullest bucket.
+// Bucket storage.  A bucket is a sequence of records numbered by its cursor; a workgroup reserves a run of positions
+// with one atomic add and record `pos` lives in the bucket's (pos / CH)-th chunk (runs are shorter than a chunk, so a
+// run straddles at most one chunk boundary).  Chunks come from one pool: chunk 0 of every bucket is assigned by the
+// host, and the thread whose reservation holds the FIRST record of chunk j takes chunk j + 1 from the pool and
+// publishes it in the bucket's table -- a whole chunk before anybody needs it, so nobody waits in practice, nothing
+// leaks, and a skewed hash distribution costs nothing: memory follows the data, not the fullest bucket.
 struct Buckets
 {
   u64 *pool;          // pool_chunks * CH * W words
@@ -640,11 +640,12 @@ struct Buckets
 
 __device__ __forceinline__ u32 chunk_of_pos (const Buckets &B, u32 pos) { return (pos / TJ_CH0) >> B.ch_shift; }
 
-// Called by whoever reserved the block starting at p0: if that block opens chunk j, claim chunk j + 1.
-__device__ __forceinline__ void bucket_claim_ahead (const Buckets &B, u32 b, u32 p0, DevCounters *ctr)
+// Called by whoever reserved records [p0, p0 + n) of bucket b (n smaller than a chunk): if the reservation holds the
+// first record of chunk j, claim chunk j + 1 (chunk 0 is pre-assigned).
+__device__ __forceinline__ void bucket_claim_ahead (const Buckets &B, u32 b, u32 p0, u32 n, DevCounters *ctr)
 {
-  const u32 j = chunk_of_pos (B, p0);
-  if (p0 != ((j * TJ_CH0) << B.ch_shift)) return;
+  const u32 j = chunk_of_pos (B, p0 + n - 1);
+  if (((j * TJ_CH0) << B.ch_shift) < p0) return;        // chunk j was opened by an earlier reservation
   if (j + 1 >= B.maxj) { ctr->overflow = 1u; return; }
   const u32 mine = atomicAdd (B.pool_next, 1u);
   if (mine >= B.pool_chunks) ctr->overflow = 1u;
@@ -679,165 +680,158 @@ __device__ __forceinline__ u64 bucket_slot (const Buckets &B, u32 b, u32 pos, bo
 
 template <int W>
 __device__ __forceinline__ void bucket_insert_slow (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, const Buckets &B, DevCounters *ctr)
-{ // a whole block for one record (cursors stay multiples of the block size); the rest is padding
-  constexpr int C = TJ_BINWORDS / W;
-  u64 w[W], z[W];
+{
+  u64 w[W];
   pack_raw<W> (c0, c1, base, len10, flag, k, w);
-  pack_null<W> (z);
   const u32 b = (u32) hash_key (c0, c1, base, len10) & (TJ_P - 1);
-  const u32 pos = atomicAdd (&B.cursors[b], (u32) C);
-  bucket_claim_ahead (B, b, pos, ctr);
+  const u32 pos = atomicAdd (&B.cursors[b], 1u);
+  bucket_claim_ahead (B, b, pos, 1u, ctr);
   const u64 at = bucket_slot (B, b, pos, true, ctr);
-  if (at != ~0ull) {
-    u64 *q = B.pool + at * W;
-    for (int j = 0; j < W; j++) q[j] = w[j];
-    for (int r = 1; r < C; r++) for (int j = 0; j < W; j++) q[r * W + j] = z[j];
-    atomicAdd (&ctr->n_null, (u64) (C - 1));
-  }
+  if (at != ~0ull) { u64 *q = B.pool + at * W; for (int j = 0; j < W; j++) q[j] = w[j]; }
 }
 
-// ---- sink 2: hash-partition into TJ_P buckets through LDS write-combining bins --------------------------------------
+// ---- sink 2: hash-partition into TJ_P buckets, in bulk ---------------------------------------------------------------
+// Tracts are appended to an LDS staging buffer as they are found (one LDS atomic per wavefront, no barrier).  When the
+// next round might not fit, the workgroup partitions what it has staged with one counting sort: count per bucket, one
+// global atomic per non-empty bucket to reserve a run, permute in place (through registers) into bucket order, and
+// write every run out contiguously.  All the fixed costs of partitioning (barriers, reservations, chunk look-ups) are
+// paid once per ~4096 records instead of once per tile.
 
 template <int W>
-struct BinLds
+struct StageLds
 {
-  u64 bins[TJ_P * TJ_BINWORDS];
-  u64 gpos[TJ_P];
-  u32 cnt[TJ_P];
-  u32 list[TJ_P];
-  u32 nfull[2], pend[2];                                // per round parity
-  u32 nnull;
+  static constexpr int S = TJ_STAGE_WORDS / W;           // records
+  u64 rec[TJ_STAGE_WORDS];
+  u64 gbase[TJ_P];                                      // pool index of the first record of the bucket's run
+  u64 gbase2[TJ_P];                                     // pool index of the part of the run that lies in the next chunk
+  u32 hist[TJ_P];
+  u32 offs[TJ_P];                                       // start of the bucket's run in the sorted staging buffer
+  u32 split[TJ_P];                                      // records of the run before the chunk boundary
+  u32 wsum[TJ_P / 64];
+  u32 n;
+  unsigned char bin[S];
 };
 
-// Thread t < TJ_P owns bin t of its workgroup.  It always holds one block of bucket t reserved in advance (`next`, the
-// result of an atomic issued at the previous flush, so its latency is never waited for) and remembers the chunk it is
-// writing to, so a flush is an LDS -> HBM copy of one 128-byte line with no global round trip on the critical path.
 template <int W, int BLOCK>
-struct BinSink
+struct StageSink
 {
-  static constexpr int C = TJ_BINWORDS / W;             // records per bin: 16, 8, 4
-  BinLds<W> &L;
+  static constexpr int S = StageLds<W>::S;
+  static constexpr int R = (S + BLOCK - 1) / BLOCK;     // staged records per thread in a partition pass
+  StageLds<W> &L;
   Buckets B; DevCounters *ctr; int k;
-  u32 next, cur_j, cur_chunk;                           // owner-thread state (registers)
-  bool unclaimed;                                       // `next` was reserved but its chunk-ahead claim is still due
-  u32 round;                                            // insertion rounds so far (workgroup-uniform)
+  u32 bound;                                            // upper bound of the records staged (workgroup-uniform)
+  u32 cur_j, cur_chunk;                                 // owner thread (tid < TJ_P): the chunk its bucket is being written to
   STAMP_MEMBER
 
   __device__ __forceinline__ void start ()
   {
-    const int tid = threadIdx.x;
-    for (int i = tid; i < TJ_P; i += BLOCK) L.cnt[i] = 0;
-    if (tid == 0) { L.nfull[0] = L.nfull[1] = 0; L.pend[0] = L.pend[1] = 0; L.nnull = 0; }
-    cur_j = TJ_EMPTY; cur_chunk = 0; next = 0; unclaimed = false; round = 0;
-    if (tid < TJ_P) { next = atomicAdd (&B.cursors[tid], (u32) C); bucket_claim_ahead (B, (u32) tid, next, ctr); }
+    if (threadIdx.x == 0) L.n = 0;
+    bound = 0; cur_j = TJ_EMPTY; cur_chunk = TJ_NOCHUNK;
     lds_barrier ();
   }
 
-  // Once per tile, right after the tile's own loads have been waited for and BEFORE the next tile's loads are issued:
-  // the reservation made at the last flush has returned by now.  Touching it here lets the compiler place its
-  // (in-order) vmcnt wait where nothing is in flight; a first use later in the tile would drain the fresh prefetch.
-  // If the reservation opened a chunk, claim the next one now: claims never wait for a bin to fill.
-  __device__ __forceinline__ void tick ()
-  {
-    asm volatile ("" : "+v"(next));
-    if (unclaimed) { bucket_claim_ahead (B, (u32) threadIdx.x, next, ctr); unclaimed = false; }
-  }
+  __device__ __forceinline__ void tick () {}
 
-  // pool index of the owner's reserved block; reserves the following one.  The new reservation is issued LAST, when
-  // the old position is dead, so that its destination can be the loop-carried register itself (a result that has to
-  // be copied into place is waited for on the spot: two microseconds per flush).
-  __device__ __forceinline__ u64 take_block (bool reserve_more)
+  // `round_max`: workgroup-uniform upper bound of the lanes that bring a record in this call
+  __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos, u32 round_max)
   {
-    const int tid = threadIdx.x;
-    const u32 p0 = next;
-    if (unclaimed) { bucket_claim_ahead (B, (u32) tid, p0, ctr); unclaimed = false; }   // (a second flush within one tile)
-    const u32 j = chunk_of_pos (B, p0);
-    if (j != cur_j) { cur_j = j; cur_chunk = bucket_chunk_id (B, (u32) tid, j, true, ctr); }   // first block here: look the chunk up
-    u64 g = ~0ull;
-    if (cur_chunk < TJ_NOCHUNK) g = (((u64) cur_chunk * TJ_CH0) << B.ch_shift) + (p0 - ((j * TJ_CH0) << B.ch_shift));
-    if (reserve_more) { next = atomicAdd (&B.cursors[tid], (u32) C); unclaimed = true; }
-    return g;
-  }
-
-  __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos)
-  {
-    const int tid = threadIdx.x;
-    u64 w[W];
-    u32 b = 0;
-    if (have) { pack_raw<W> (c0, c1, base, len10, flag, k, w); b = (u32) hash_key (c0, c1, base, len10) & (TJ_P - 1); }
-    bool pending = have;
-    for (;;) {
-      const u32 par = round & 1u;
-      round++;
-      if (pending) {
-        const u32 s = atomicAdd (&L.cnt[b], 1u);
-        if (s < (u32) C) {
-          u64 *q = L.bins + (b * C + s) * W;
+    if (bound + round_max > (u32) S) { partition (); bound = 0; }
+    bound += round_max;
+    const u64 mask = __ballot (have);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll ((long long) mask) - 1;
+    u32 at = 0;
+    if (lane == leader) at = atomicAdd (&L.n, (u32) __popcll (mask));
+    at = __shfl (at, leader) + (u32) __popcll (mask & ((1ull << lane) - 1ull));
+    if (have) {
+      u64 w[W];
+      pack_raw<W> (c0, c1, base, len10, flag, k, w);
 #pragma unroll
-          for (int j = 0; j < W; j++) q[j] = w[j];
-          pending = false;
-        }
-        else L.pend[par] = 1u;                          // bin full: again after the flush
-      }
-      PSTAMP (9);
-      lds_barrier ();                                   // (1) every insert of the round is in LDS
-      PSTAMP (10);
-      if (tid == 0) { L.nfull[par ^ 1u] = 0; L.pend[par ^ 1u] = 0; }
-      {                                                 // every full bin goes out as one 128-byte line of its bucket
-        const bool full = (tid < TJ_P) && (L.cnt[tid] >= (u32) C);
-        const u64 fm = __ballot (full);
-        if (fm) {                                       // one LDS atomic per wavefront for the list position
-          const int lane = tid & 63, leader = __ffsll ((long long) fm) - 1;
-          u32 lb = 0;
-          if (lane == leader) lb = atomicAdd (&L.nfull[par], (u32) __popcll (fm));
-          lb = __shfl (lb, leader);
-          if (full) {
-            L.list[lb + (u32) __popcll (fm & ((1ull << lane) - 1ull))] = (u32) tid;
-            L.cnt[tid] = 0;                              // (before take_block: see the note there about waits)
-            L.gpos[tid] = take_block (true);
-          }
-        }
-      }
-      PSTAMP (11);
-      lds_barrier ();                                   // (2) list of full bins complete
-      PSTAMP (12);
-      const int nfull = (int) L.nfull[par];
-      const bool again = L.pend[par] != 0u;
-      for (int i = tid; i < nfull * TJ_BINWORDS; i += BLOCK) {
-        const u32 bin = L.list[i / TJ_BINWORDS];
-        const int wj = i % TJ_BINWORDS;
-        const u64 g = L.gpos[bin];
-#ifndef TJ_EXP_NOSTORE
-        if (g != ~0ull) B.pool[g * W + wj] = L.bins[bin * TJ_BINWORDS + wj];
-#endif
-      }
-      PSTAMP (13);
-      lds_barrier ();                                   // (3) the copied bins may be refilled from here on
-      PSTAMP (14);
-      if (!again) break;
+      for (int j = 0; j < W; j++) L.rec[at * W + j] = w[j];
+      L.bin[at] = (unsigned char) ((u32) hash_key (c0, c1, base, len10) & (TJ_P - 1));
     }
   }
 
-  __device__ __forceinline__ void finish ()
-  { // the reserved block of every bin takes what is left in the bin, padded with null records
-    const int tid = threadIdx.x;
-    tick ();
+  __device__ __forceinline__ void partition ()
+  {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    lds_barrier ();                                     // every append so far is in LDS
+    const u32 n = L.n;
+    if (tid < TJ_P) L.hist[tid] = 0;
+    lds_barrier ();
+    u64 w[R][W];
+    u32 rk[R], bb[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {                       // my records, and their rank inside their bucket
+      const u32 i = (u32) tid + (u32) r * BLOCK;
+      bb[r] = TJ_EMPTY;
+      if (i < n) {
+        bb[r] = L.bin[i];
+#pragma unroll
+        for (int j = 0; j < W; j++) w[r][j] = L.rec[i * W + j];
+        rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
+      }
+    }
+    lds_barrier ();
+    u32 cnt = 0, incl = 0;
+    if (tid < TJ_P) {                                   // exclusive prefix of the bucket counts (waves 0..3)
+      cnt = L.hist[tid];
+      incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up (incl, o); if (lane >= o) incl += y; }
+      if (lane == 63) L.wsum[wave] = incl;
+    }
     lds_barrier ();
     if (tid < TJ_P) {
-      const u32 n = min (L.cnt[tid], (u32) C);
-      const u64 g = take_block (false);
-      if (g != ~0ull) {
-        u64 z[W];
-        pack_null<W> (z);
-        u64 *q = B.pool + g * W;
-        for (u32 i = 0; i < n * W; i++) q[i] = L.bins[tid * TJ_BINWORDS + i];
-        for (u32 r = n; r < (u32) C; r++) for (int j = 0; j < W; j++) q[r * W + j] = z[j];
-        atomicAdd (&L.nnull, (u32) C - n);
+      u32 wbase = 0;
+      for (int v = 0; v < wave; v++) wbase += L.wsum[v];
+      L.offs[tid] = wbase + incl - cnt;
+      if (cnt) {                                        // reserve the bucket's run and find out where it lives
+        const u32 ch = (u32) TJ_CH0 << B.ch_shift;
+        const u32 p0 = atomicAdd (&B.cursors[tid], cnt);
+        bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
+        const u32 j0 = chunk_of_pos (B, p0), j1 = chunk_of_pos (B, p0 + cnt - 1);
+        if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (B, (u32) tid, j0, true, ctr); }
+        L.gbase[tid] = (cur_chunk == TJ_NOCHUNK) ? ~0ull : (u64) cur_chunk * ch + (p0 - j0 * ch);
+        u32 sp = cnt;
+        u64 g2 = ~0ull;
+        if (j1 != j0) {                                 // the run crosses into the next chunk
+          sp = j1 * ch - p0;
+          cur_j = j1; cur_chunk = bucket_chunk_id (B, (u32) tid, j1, true, ctr);
+          if (cur_chunk != TJ_NOCHUNK) g2 = (u64) cur_chunk * ch;
+        }
+        L.split[tid] = sp; L.gbase2[tid] = g2;
       }
     }
     lds_barrier ();
-    if (tid == 0 && L.nnull) atomicAdd (&ctr->n_null, (u64) L.nnull);
+#pragma unroll
+    for (int r = 0; r < R; r++)                          // in-place permutation into bucket order (records are in registers)
+      if (bb[r] != TJ_EMPTY) {
+        const u32 d = L.offs[bb[r]] + rk[r];
+#pragma unroll
+        for (int j = 0; j < W; j++) L.rec[d * W + j] = w[r][j];
+        L.bin[d] = (unsigned char) bb[r];
+      }
+    lds_barrier ();
+#pragma unroll
+    for (int r = 0; r < R; r++) {                       // sorted slot i -> its place in the bucket's run (coalesced per run)
+      const u32 i = (u32) tid + (u32) r * BLOCK;
+      if (i < n) {
+        const u32 b = L.bin[i], o = i - L.offs[b], sp = L.split[b];
+        const u64 g = (o < sp) ? L.gbase[b] : L.gbase2[b];
+        if (g != ~0ull) {
+          u64 *q = B.pool + (g + (o < sp ? o : o - sp)) * W;
+#pragma unroll
+          for (int j = 0; j < W; j++) q[j] = L.rec[i * W + j];
+        }
+      }
+    }
+    lds_barrier ();
+    if (tid == 0) L.n = 0;
+    lds_barrier ();
   }
+
+  __device__ __forceinline__ void finish () { partition (); }
 };
 
 #define TJ_SB_BLOCK 512
@@ -851,8 +845,8 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
 {
   __shared__ TileLds<TJ_SB_BLOCK, TJ_SB_TILE> T;
   __shared__ uint4 raw[TileLds<TJ_SB_BLOCK, TJ_SB_TILE>::NCHUNK];
-  __shared__ BinLds<W> B;
-  BinSink<W, TJ_SB_BLOCK> sink = {B, BK, ctr, k, 0u, 0u, 0u, false, 0u};
+  __shared__ StageLds<W> SL;
+  StageSink<W, TJ_SB_BLOCK> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
   sink.start ();
   scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap);
   sink.finish ();
@@ -1545,15 +1539,16 @@ static int ensure_buckets (tjamd_counter *c, u64 add, int grid)
 {
   if (c->ch_shift < 0) {                                // chunk size: at most ~16 k chunks for this many records
     const u64 units = add / (16384ull * TJ_CH0);
-    int sft = 0;
+    int sft = 2;                                        // a chunk holds more than one partition pass stages (4096 records)
     while ((1ull << sft) < units) sft++;
     c->ch_shift = sft;
   }
   const u64 ch = (u64) TJ_CH0 << c->ch_shift;
-  const u64 pad_bucket = (u64) grid * TJ_BINWORDS;      // each workgroup leaves at most one block per bucket partly empty
+  const u64 pad_bucket = 0;                             // (no padding records any more)
+  (void) grid;
   // one chunk per bucket is always claimed ahead of the cursor
-  const u64 need_chunks = c->chunk_bound + (add + pad_bucket * TJ_P + ch - 1) / ch + 2 * TJ_P;
-  const u64 need_maxj = (c->bucket_bound + add + pad_bucket + ch - 1) / ch + 3;   // worst case: everything in one bucket
+  const u64 need_chunks = c->chunk_bound + (add + ch - 1) / ch + 2 * TJ_P;
+  const u64 need_maxj = (c->bucket_bound + add + ch - 1) / ch + 3;      // worst case: everything in one bucket
   if (need_chunks >= TJ_NOCHUNK || need_maxj >= (1ull << 31)) return set_err (TJAMD_ERR_CAPACITY, "batch too large for the chunk table");
   int rc = ensure (c->pool, (size_t) need_chunks * ch * c->W * 8, c->stream, std::min<size_t> ((size_t) (c->chunk_bound * ch * c->W * 8), c->pool.cap));
   if (rc) return rc;
@@ -1731,7 +1726,7 @@ extern "C" int tjamd_upload_raw (tjamd_counter *c, const hopo_element *elems, lo
   if (n == 0) return TJAMD_OK;
   HIPCHK (hipSetDevice (c->device));
   int rc = sync_counters (c);
-  if (!rc) rc = ensure_buckets (c, (u64) n * TJ_BINWORDS, 0);   // one block per record
+  if (!rc) rc = ensure_buckets (c, (u64) n, 0);
   if (!rc) rc = ensure (c->stage, (size_t) n * 40, c->stream);
   if (rc) return rc;
   HIPCHK (hipMemcpyAsync (c->stage.p, elems, (size_t) n * 40, hipMemcpyHostToDevice, c->stream));
