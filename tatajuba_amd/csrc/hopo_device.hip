@@ -918,7 +918,7 @@ __global__ void table_relayout_kernel (const u32 *__restrict__ old, u32 old_maxj
 // entirely in one round, so rounds never split a count.
 
 #define AG_S        4096                // table slots
-#define AG_CLOSE_AT 2048                // stop admitting new keys beyond this many (one batch may add 1024 more)
+#define AG_CLOSE_AT 1792                // stop admitting new keys beyond this many (the count is one batch stale: up to 2048 more)
 #define AG_BLOCK    1024
 
 struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow; };
@@ -931,7 +931,7 @@ struct AggLds
   u32 k2[AG_S];                         // base | stored length << 2
   u32 cf[AG_S];                         // occurrences as read (canon_flag 1)
   u32 cr[AG_S];                         // occurrences reverse-complemented (canon_flag 2)
-  u32 n_claimed, n_ovf, closed, total;
+  u32 n_claimed, n_ovf, closed[2], total;
   u32 wsum[AG_BLOCK / 64];
 };
 
@@ -966,6 +966,123 @@ __device__ __forceinline__ bool agg_insert (AggLds &L, u64 c0, u64 c1, u32 k2, u
   return false;
 }
 
+// ---- W = 1 (k <= 12): the whole reduction key is the record word without its strand flag, so one 64-bit LDS
+// compare-and-swap per probe decides "new key / same key / other key" -- no tag, no publish step, no key read-back.
+#define AG1_S        8192
+#define AG1_CLOSE_AT 5632                // the count is one batch stale: up to 2048 more may be claimed
+
+struct Agg1Lds
+{
+  u64 key[AG1_S];                       // record >> 2 (never 0: the stored length of a tract is >= 2)
+  u32 cf[AG1_S], cr[AG1_S];
+  u32 n_claimed, n_ovf, closed[2], total;
+  u32 wsum[AG_BLOCK / 64];
+};
+
+__global__ __launch_bounds__ (AG_BLOCK)
+void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+{
+  __shared__ Agg1Lds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 bkt = blockIdx.x;
+  u32 n = BK.cursors[bkt];
+  const u64 km = kmask (k);
+
+  while (n > 0) {
+    for (int i = tid; i < AG1_S; i += AG_BLOCK) { L.key[i] = 0; L.cf[i] = 0; L.cr[i] = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.closed[0] = L.closed[1] = 0; }
+    __syncthreads ();
+
+    u64 wn = 0;
+    bool vn = false;
+    u32 cj = TJ_EMPTY, cc = TJ_NOCHUNK;
+    auto fetch = [&] (u32 idx) {
+      vn = false;
+      if (idx < n) {
+        const u32 j = chunk_of_pos (BK, idx);
+        if (j != cj) { cj = j; cc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
+        if (cc != TJ_NOCHUNK) { vn = true; wn = BK.pool[(((u64) cc * TJ_CH0) << BK.ch_shift) + (idx - ((j * TJ_CH0) << BK.ch_shift))]; }
+      }
+    };
+    fetch ((u32) tid);
+    u32 par = 0;
+    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK, par ^= 1u) {
+      const u64 w = wn;
+      const bool valid = vn;
+      fetch (b0 + AG_BLOCK + tid);
+      if (tid == 0) L.closed[par ^ 1u] = (L.n_claimed > AG1_CLOSE_AT) ? 1u : 0u;
+      const bool closed = L.closed[par] != 0u;
+      if (valid && (w & 3ull) != 3ull) {
+        const u64 key = w >> 2;
+        u32 h = (u32) key ^ __builtin_amdgcn_alignbit ((u32) (key >> 32), (u32) (key >> 32), 17);
+        h *= 0x9E3779B1u; h ^= h >> 15;
+        u32 slot = h & (AG1_S - 1);
+        bool done = false;
+        for (u32 probes = 0; probes < AG1_S && !done; probes++) {
+          u64 old;
+          if (!closed) {
+            old = atomicCAS ((unsigned long long *) &L.key[slot], 0ull, (unsigned long long) key);
+            if (old == 0ull) { atomicAdd (&L.n_claimed, 1u); old = key; }
+          }
+          else old = L.key[slot];
+          if (old == key) { atomicAdd ((w & 2ull) ? &L.cr[slot] : &L.cf[slot], 1u); done = true; }
+          else if (old == 0ull) break;                  // closed table, key absent
+          else slot = (slot + 1u) & (AG1_S - 1);
+        }
+        if (!done) {
+          const u32 o = atomicAdd (&L.n_ovf, 1u);
+          const u64 at = bucket_slot (BK, bkt, o, false, nullptr);
+          if (at != ~0ull) BK.pool[at] = w;
+        }
+      }
+      lds_barrier ();
+    }
+    __syncthreads ();
+
+    u32 mine = 0;
+    u64 metas[AG1_S / AG_BLOCK];
+#pragma unroll
+    for (int r = 0; r < AG1_S / AG_BLOCK; r++) {
+      const int slot = tid + r * AG_BLOCK;
+      metas[r] = 0;
+      if (L.key[slot]) {
+        const u32 cf = L.cf[slot], cr = L.cr[slot];
+        const u64 flag = (cf ? 1ull : 0ull) | (cr ? 2ull : 0ull);
+        const u64 cnt = ((u64) cf + (u64) cr) & 0xFFFFFull;
+        const int scnt = (cnt & 0x80000ull) ? (int) cnt - 0x100000 : (int) cnt;
+        if (remove_biased ? (flag == 3ull) : (scnt > 1)) {
+          const u64 key = L.key[slot];                  // len | ctx1 << 10 | ctx0 << (10 + 2k) | base << (10 + 4k)
+          metas[r] = ((key >> (10 + 4 * k)) & 1ull) | ((key & 0x3FFull) << TJ_META_LEN_SHIFT) | (cnt << TJ_META_COUNT_SHIFT) |
+                     (0xffeull << TJ_META_MISM_SHIFT) | (flag << TJ_META_FLAG_SHIFT);
+          mine++;
+        }
+      }
+    }
+    u32 x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up (x, o); if (lane >= o) x += y; }
+    if (lane == 63) L.wsum[wave] = x;
+    __syncthreads ();
+    u32 wbase = 0, total = 0;
+    for (int wv = 0; wv < AG_BLOCK / 64; wv++) { const u32 sm = L.wsum[wv]; if (wv < wave) wbase += sm; total += sm; }
+    if (tid == 0) L.total = total ? atomicAdd (&fin->n_kept, total) : 0u;
+    __syncthreads ();
+    u64 at = (u64) L.total + wbase + x - mine;
+#pragma unroll
+    for (int r = 0; r < AG1_S / AG_BLOCK; r++)
+      if (metas[r]) {
+        const u64 key = L.key[tid + r * AG_BLOCK];
+        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (key >> (10 + 2 * k)) & km; q[1] = (key >> 10) & km; q[2] = metas[r]; }
+        else fin->overflow = 1u;
+        at++;
+      }
+    __threadfence_block ();
+    __syncthreads ();
+    n = L.n_ovf;
+    __syncthreads ();
+  }
+}
+
 template <int W>
 __global__ __launch_bounds__ (AG_BLOCK)
 void aggregate_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
@@ -977,32 +1094,37 @@ void aggregate_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ k
 
   while (n > 0) {
     for (int i = tid; i < AG_S; i += AG_BLOCK) { L.tag[i] = 0; L.cf[i] = 0; L.cr[i] = 0; }
-    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.closed = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.closed[0] = L.closed[1] = 0; }
     __syncthreads ();
 
     u64 wn[W];                                          // records are fetched one batch ahead of their use
     bool vn = false;
+    u32 cj = TJ_EMPTY, cc = TJ_NOCHUNK;                 // chunk this lane is reading from (changes once per chunk)
     auto fetch = [&] (u32 idx) {
       vn = false;
       if (idx < n) {
-        const u64 at = bucket_slot (BK, bkt, idx, false, nullptr);
-        if (at != ~0ull) {
+        const u32 j = chunk_of_pos (BK, idx);
+        if (j != cj) { cj = j; cc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
+        if (cc != TJ_NOCHUNK) {
+          const u64 at = (((u64) cc * TJ_CH0) << BK.ch_shift) + (idx - ((j * TJ_CH0) << BK.ch_shift));
           vn = true;
 #pragma unroll
-          for (int j = 0; j < W; j++) wn[j] = BK.pool[at * W + j];
+          for (int j2 = 0; j2 < W; j2++) wn[j2] = BK.pool[at * W + j2];
         }
       }
     };
     fetch ((u32) tid);
-    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK) {
+    u32 par = 0;
+    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK, par ^= 1u) {
       u64 w[W];
 #pragma unroll
       for (int j = 0; j < W; j++) w[j] = wn[j];
       const bool valid = vn;
       fetch (b0 + AG_BLOCK + tid);                      // leftovers are written below b0 + AG_BLOCK: never where this reads
-      if (tid == 0) L.closed = (L.n_claimed > AG_CLOSE_AT) ? 1u : 0u;
-      __syncthreads ();                                 // table state decided for the batch
-      const bool closed = L.closed != 0u;
+      // One barrier per batch.  Thread 0 decides here whether the NEXT batch may still admit keys; the count it sees
+      // may miss the claims other waves are still making in the previous batch and all of this one (<= 2048).
+      if (tid == 0) L.closed[par ^ 1u] = (L.n_claimed > AG_CLOSE_AT) ? 1u : 0u;
+      const bool closed = L.closed[par] != 0u;          // decided during the previous batch, stable since its barrier
       if (valid) {
         u64 c0, c1; u32 base, len10, flag;
         unpack_raw<W> (w, k, c0, c1, base, len10, flag);
@@ -1015,8 +1137,9 @@ void aggregate_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ k
           }
         }
       }
-      __syncthreads ();                                 // n_claimed is exact before the next decision
+      lds_barrier ();
     }
+    __syncthreads ();
 
     // emit this round's keys: filter, then one global atomic per workgroup
     u32 mine = 0;
@@ -1810,7 +1933,7 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   HIPCHK (hipMemsetAsync (c->d_fin, 0, sizeof (FinCounts), c->stream));
   const Buckets BK = make_buckets (c);
   switch (c->W) {
-    case 1: hipLaunchKernelGGL (aggregate_kernel<1>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
+    case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
     case 2: hipLaunchKernelGGL (aggregate_kernel<2>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
     default: hipLaunchKernelGGL (aggregate_kernel<4>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
   }
