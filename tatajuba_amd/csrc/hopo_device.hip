@@ -129,17 +129,20 @@ __device__ __forceinline__ void classify_word (u32 x, u32 prev_byte, u32 &code8,
 // caller redoes the chunk with classify_word, which also produces the non-ACGTU plane).
 __device__ __forceinline__ void classify_word_fast (u32 x, u32 prev_word, u32 &code8, u32 &start4, u32 &sent4, u32 &bad)
 {
+  // 2-bit codes, packed with one dot product (byte j * 4^j)
   const u32 c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
-  u32 t = c | (c >> 6);
-  code8 = (t | (t >> 12)) & 0xFFu;
+  code8 = __builtin_amdgcn_udot4 (c, 0x40100401u, 0u, false);
+  // delimiter: the only byte of the fast path without bit 6
+  const u32 s = (~x >> 6) & 0x01010101u;
+  sent4 = __builtin_amdgcn_udot4 (s, 0x08040201u, 0u, false);
+  // validation: every byte must be the letter its code stands for, or '\n' where bit 6 is clear
   const u32 expect = __builtin_amdgcn_perm (0u, 0x54474341u, c);      // 'A','C','G','T' indexed by the code
-  u32 zs = zero_bytes (x ^ 0x0A0A0A0Au);                             // 0x80 per delimiter byte
-  bad = (x ^ expect) & ~(zs | (zs - (zs >> 7)));                     // ignore delimiter bytes (0x80 | 0x7f = 0xff)
-  zs >>= 7; t = zs | (zs >> 7);
-  sent4 = (t | (t >> 14)) & 0xFu;
-  u32 ze = zero_bytes (x ^ __builtin_amdgcn_alignbit (x, prev_word, 24)) >> 7;   // byte equals its predecessor
-  t = ze | (ze >> 7);
-  start4 = ((t | (t >> 14)) & 0xFu) ^ 0xFu;
+  const u32 m = (s << 8) - s;                                        // 0xff per delimiter candidate
+  bad = (m & (x ^ 0x0A0A0A0Au)) | (~m & (x ^ expect));
+  // run start: byte differs from its predecessor
+  const u32 d = x ^ __builtin_amdgcn_alignbit (x, prev_word, 24);
+  const u32 nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) >> 7) & 0x01010101u;
+  start4 = __builtin_amdgcn_udot4 (nz, 0x08040201u, 0u, false);
 }
 
 // ---- diagnostic build only (-DTJ_STAMPS=1): where does a tile's time go?  Never enabled in the product library. ----
@@ -614,6 +617,17 @@ __device__ __forceinline__ u64 hash_key (u64 c0, u64 c1, u32 base, u32 len10)
   return ((u64) tag << 32) | h;
 }
 
+// bucket of a key: byte-wise dot products (full-rate v_dot4_u32_u8) instead of multiplies; the flank k-mers are close to
+// uniform, so a weighted byte sum spreads them evenly enough over 256 buckets (the tables inside a bucket use hash_key)
+__device__ __forceinline__ u32 bucket_of_key (u64 c0, u64 c1, u32 base, u32 len10)
+{
+  u32 h = __builtin_amdgcn_udot4 ((u32) c0, 0x6D2B4F0Bu, base | (len10 << 2), false);
+  h = __builtin_amdgcn_udot4 ((u32) (c0 >> 32), 0x1D59A735u, h, false);
+  h = __builtin_amdgcn_udot4 ((u32) c1, 0xC5A34D17u, h, false);
+  h = __builtin_amdgcn_udot4 ((u32) (c1 >> 32), 0x3B7F9165u, h, false);
+  return (h ^ (h >> 8)) & 255u;
+}
+
 #define TJ_P        256                 // hash buckets
 #define TJ_PBITS    8
 #define TJ_STAGE_WORDS 4096             // 64-bit words of records a workgroup stages in LDS between partition passes
@@ -683,7 +697,7 @@ __device__ __forceinline__ void bucket_insert_slow (u64 c0, u64 c1, u32 base, u3
 {
   u64 w[W];
   pack_raw<W> (c0, c1, base, len10, flag, k, w);
-  const u32 b = (u32) hash_key (c0, c1, base, len10) & (TJ_P - 1);
+  const u32 b = bucket_of_key (c0, c1, base, len10);
   const u32 pos = atomicAdd (&B.cursors[b], 1u);
   bucket_claim_ahead (B, b, pos, 1u, ctr);
   const u64 at = bucket_slot (B, b, pos, true, ctr);
@@ -748,7 +762,7 @@ struct StageSink
       pack_raw<W> (c0, c1, base, len10, flag, k, w);
 #pragma unroll
       for (int j = 0; j < W; j++) L.rec[at * W + j] = w[j];
-      L.bin[at] = (unsigned char) ((u32) hash_key (c0, c1, base, len10) & (TJ_P - 1));
+      L.bin[at] = (unsigned char) bucket_of_key (c0, c1, base, len10);
     }
   }
 
