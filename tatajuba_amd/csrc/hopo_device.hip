@@ -79,6 +79,7 @@ struct TileLds
   unsigned short cand[MAXCAND];
   unsigned short fl[NCHUNK + 4];                         // per chunk: first byte | last byte << 8
   u32 ncand;
+  u32 odd[2];                                            // per tile parity: some byte of the tile is neither ACGT nor '\n'
 };
 
 struct DevCounters
@@ -178,6 +179,19 @@ extern "C" int tjamd_debug_stamps (unsigned long long *out, int reset)
 #define STAMP_MEMBER
 #endif
 
+// inclusive prefix sum over the 64 lanes of a wavefront with DPP adds (row shifts inside 16-lane rows, then the two
+// row broadcasts): 6 VALU instructions instead of 6 ds_bpermute round trips
+__device__ __forceinline__ u32 wave_inclusive_scan (u32 x)
+{
+  x += (u32) __builtin_amdgcn_update_dpp (0, (int) x, 0x111, 0xF, 0xF, true);   // row_shr:1
+  x += (u32) __builtin_amdgcn_update_dpp (0, (int) x, 0x112, 0xF, 0xF, true);   // row_shr:2
+  x += (u32) __builtin_amdgcn_update_dpp (0, (int) x, 0x114, 0xF, 0xF, true);   // row_shr:4
+  x += (u32) __builtin_amdgcn_update_dpp (0, (int) x, 0x118, 0xF, 0xF, true);   // row_shr:8
+  x += (u32) __builtin_amdgcn_update_dpp (0, (int) x, 0x142, 0xA, 0xF, true);   // row_bcast:15 -> rows 1 and 3
+  x += (u32) __builtin_amdgcn_update_dpp (0, (int) x, 0x143, 0xC, 0xF, true);   // row_bcast:31 -> rows 2 and 3
+  return x;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding global stores and
 // atomics (vmcnt(0), microseconds each under load); inside the scan nothing written to HBM is read back in the same
 // launch, so the bucket writes and the cursor atomics are left in flight across barriers.
@@ -194,6 +208,21 @@ __device__ __forceinline__ u64 bits64 (const u32 *a, int bitpos)
   u32 lo = __funnelshift_r (x0, x1, sh);
   u32 hi = __funnelshift_r (x1, x2, sh);
   return ((u64) hi << 32) | lo;
+}
+
+// 32 bits of a bit array starting at bit position `bitpos` (array padded by >= 1 word)
+__device__ __forceinline__ u32 bits32 (const u32 *a, int bitpos)
+{
+  const int w = bitpos >> 5;
+  return __builtin_amdgcn_alignbit (a[w + 1], a[w], (u32) bitpos & 31u);
+}
+
+// reverse complement of a k-mer of at most 16 bases held in 32 bits
+__device__ __forceinline__ u32 revcomp_k32 (u32 x, int k)
+{
+  u32 y = __brev (~x);
+  y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+  return y >> (32 - 2 * k);
 }
 
 __device__ __forceinline__ u64 kmask (int k) { return (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1ull); }
@@ -332,6 +361,8 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
   const u64 kbits = (1ull << k) - 1ull;                 // k <= 32
 
   long tile = blockIdx.x;
+  if (tid == 0) { T.odd[0] = 0; T.odd[1] = 0; }
+  lds_barrier ();
   if (tile < n_tiles) {
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
@@ -346,7 +377,8 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     const long g0 = tile * (long) TILE - TJ_HL;         // stream position of window byte 0 (may be negative)
 
     // ---- phase 1: classify the prefetched chunks into LDS, then prefetch the next tile ------------------------
-    if (tid == 0) T.ncand = 0;
+    const u32 tpar = (u32) ((tile / gridDim.x) & 1);
+    if (tid == 0) { T.ncand = 0; T.odd[tpar ^ 1u] = 0; }
     if (tid < 4) { T.code[G::CODEW - 4 + tid] = 0; T.start[G::MASKW - 4 + tid] = 0; T.sent[G::MASKW - 4 + tid] = 0xFFFFFFFFu; T.inval[G::MASKW - 4 + tid] = 0; }
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's chunks of the tile have landed in raw
 #pragma unroll
@@ -374,6 +406,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
           prevw = w[j];
         }
         if (__builtin_expect (bad != 0u, 0)) {          // lower case, U, N, anything else: exact classification
+          T.odd[tpar] = 1u;
           u32 prev = w[0] & 0xFFu;
           code32 = st16 = se16 = iv16 = 0;
           for (int j = 0; j < 4; j++) {
@@ -429,12 +462,10 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
       cand &= ~(u32) reinterpret_cast<unsigned short *> (T.sent)[p0 >> 4];  // a run of delimiters is not a tract
       // one LDS atomic per wavefront (512 same-address atomics serialise): exclusive prefix of the lane counts
       const u32 n = (u32) __popc (cand);
-      u32 incl = n;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up (incl, o); if ((tid & 63) >= o) incl += y; }
+      const u32 incl = wave_inclusive_scan (n);
       u32 wbase = 0;
       if ((tid & 63) == 63 && incl) wbase = atomicAdd (&T.ncand, incl);
-      wbase = __shfl (wbase, 63);
+      wbase = (u32) __builtin_amdgcn_readlane ((int) wbase, 63);
       u32 at = wbase + incl - n;
       while (cand) { int b = __ffs ((int) cand) - 1; cand &= cand - 1u; if (at < (u32) G::MAXCAND) T.cand[at] = (unsigned short) (p0 + b); at++; }
     }
@@ -447,6 +478,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
 
     // ---- phase 3: one lane per candidate --------------------------------------------------------------------
     const int ncand = min ((int) T.ncand, G::MAXCAND);
+    const bool tile_odd = T.odd[tpar] != 0u;            // some byte of this tile needed the exact classification
     for (int cb0 = 0; cb0 < ncand; cb0 += BLOCK) {
       const int ci = cb0 + tid;
       bool have = false;
@@ -456,23 +488,49 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
         const int s = T.cand[ci];
         const long gs = g0 + s;
         int e = -1;                                   // run end: first run start after s
-        for (int p = s + 1; p < G::WIN; p += 64) {
-          u64 ns = bits64 (T.start, p);
-          if (ns) { e = p + __ffsll ((long long) ns) - 2; break; }
+        {
+          const u64 ns = bits64 (T.start, s + 1);
+          if (ns) e = s + __ffsll ((long long) ns) - 1;
+          else for (int p = s + 65; p < G::WIN; p += 64) {
+            const u64 n2 = bits64 (T.start, p);
+            if (n2) { e = p + __ffsll ((long long) n2) - 2; break; }
+          }
         }
-        const bool inval = (T.inval[s >> 5] >> (s & 31)) & 1u;
+        const bool inval = tile_odd && ((T.inval[s >> 5] >> (s & 31)) & 1u);
         bool ok;
         long len;
         u64 left = 0, right = 0;
         u32 cb = 0, linv = 0, rinv = 0;
         if (e >= 0 && e + k < G::WIN) {               // everything needed is in LDS
           len = e - s + 1;
-          ok = ((bits64 (T.sent, s - k) & kbits) == 0ull) && ((bits64 (T.sent, e + 1) & kbits) == 0ull);
-          if (ok && !inval) {
-            left = bits64 (T.code, 2 * (s - k)) & km;
-            right = bits64 (T.code, 2 * (e + 1)) & km;
-            cb = (T.code[s >> 4] >> (2 * (s & 15))) & 3u;
-            if (cb >= 2u) { linv = (u32) (bits64 (T.inval, s - k) & kbits); rinv = (u32) (bits64 (T.inval, e + 1) & kbits); }
+          if (Sink::K32) {                            // k <= 12: flanks, masks and k-mers fit 32-bit arithmetic
+            const u32 kb32 = (1u << k) - 1u, km32 = (1u << (2 * k)) - 1u;
+            ok = (((bits32 (T.sent, s - k) | bits32 (T.sent, e + 1)) & kb32) == 0u);
+            if (ok && !inval) {
+              u32 l32 = bits32 (T.code, 2 * (s - k)) & km32, r32 = bits32 (T.code, 2 * (e + 1)) & km32;
+              cb = (T.code[s >> 4] >> (2 * (s & 15))) & 3u;
+              if (cb < 2u) { c0 = l32; c1 = r32; base = cb; flag = 1u; }
+              else {
+                if (tile_odd) {
+                  linv = bits32 (T.inval, s - k) & kb32; rinv = bits32 (T.inval, e + 1) & kb32;
+                  if (linv | rinv) { l32 |= (u32) spread_pairs (linv); r32 |= (u32) spread_pairs (rinv); }
+                }
+                c0 = revcomp_k32 (r32, k); c1 = revcomp_k32 (l32, k); base = 3u - cb; flag = 2u;
+              }
+              len10 = (u32) len & 0x3FFu;
+              pos = (u64) gs;
+              have = true;
+              ok = false;                             // (record complete: skip the generic tail below)
+            }
+          }
+          else {
+            ok = ((bits64 (T.sent, s - k) & kbits) == 0ull) && ((bits64 (T.sent, e + 1) & kbits) == 0ull);
+            if (ok && !inval) {
+              left = bits64 (T.code, 2 * (s - k)) & km;
+              right = bits64 (T.code, 2 * (e + 1)) & km;
+              cb = (T.code[s >> 4] >> (2 * (s & 15))) & 3u;
+              if (cb >= 2u && tile_odd) { linv = (u32) (bits64 (T.inval, s - k) & kbits); rinv = (u32) (bits64 (T.inval, e + 1) & kbits); }
+            }
           }
         }
         else {                                        // tract runs past the window: walk the stream (rare)
@@ -539,6 +597,7 @@ __device__ bool stale_context (const uint8_t *__restrict__ seq, long n_bytes, lo
 
 struct ListSink
 {
+  static constexpr bool K32 = false;
   u64 *out; u64 cap; DevCounters *ctr;
   STAMP_MEMBER
   __device__ __forceinline__ void tick () {}
@@ -729,6 +788,7 @@ struct StageLds
 template <int W, int BLOCK>
 struct StageSink
 {
+  static constexpr bool K32 = (W == 1);                 // k <= 12: the scan may use 32-bit k-mer arithmetic
   static constexpr int S = StageLds<W>::S;
   static constexpr int R = (S + BLOCK - 1) / BLOCK;     // staged records per thread in a partition pass
   StageLds<W> &L;
@@ -790,9 +850,7 @@ struct StageSink
     u32 cnt = 0, incl = 0;
     if (tid < TJ_P) {                                   // exclusive prefix of the bucket counts (waves 0..3)
       cnt = L.hist[tid];
-      incl = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up (incl, o); if (lane >= o) incl += y; }
+      incl = wave_inclusive_scan (cnt);
       if (lane == 63) L.wsum[wave] = incl;
     }
     lds_barrier ();
