@@ -908,7 +908,7 @@ struct StageSink
 
 #define TJ_SB_BLOCK 512
 #define TJ_SB_TILE  8192
-#define TJ_SB_WG_PER_CU 3               // ~50 KB of LDS per workgroup (registers may allow only 2: the third then queues)
+#define TJ_SB_WG_PER_CU 2               // resident workgroups per CU (65 KB of LDS each); the grid is exactly one resident wave
 
 template <int W>
 __global__ __launch_bounds__ (TJ_SB_BLOCK)
