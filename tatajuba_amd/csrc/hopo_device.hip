@@ -908,7 +908,7 @@ struct StageSink
 
 #define TJ_SB_BLOCK 512
 #define TJ_SB_TILE  8192
-#define TJ_SB_WG_PER_CU 2               // resident workgroups per CU (65 KB of LDS each); the grid is exactly one resident wave
+#define TJ_SB_WG_PER_CU 3               // grid = 3 workgroups per CU: 2 are resident (65 KB of LDS each), the queued third evens out the tail
 
 template <int W>
 __global__ __launch_bounds__ (TJ_SB_BLOCK)
