@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per sample (per GPU)")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--read-len-max", type=int, default=0, help="> read-len: ragged reads, length uniform in [read-len, read-len-max]")
     ap.add_argument("--genome", type=int, default=5_000_000)
     ap.add_argument("--kmer", type=int, default=10)
     ap.add_argument("--min-tract", type=int, default=3)
@@ -50,15 +51,24 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available() or tj.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("TATAJUBA_BENCH_BACKEND", "nccl")    # "gloo" only to rehearse N > 1 on a one-GPU box
+    if local >= ndev:
+        if backend == "nccl":
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+        local = local % ndev
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     k, m, L = args.kmer, args.min_tract, args.read_len
     # one sample per rank: same genome, per-sample tract-length variants and read seeds (SURVEY 8d config 4 recipe)
-    host = tj.synth_stream(args.reads, L, args.genome, seed_reads=0x7A7A1000 + rank,
+    host = tj.synth_stream(args.reads, L, args.genome, seed_reads=0x7A7A1000 + rank, read_len_max=args.read_len_max,
                            variant_seed=(rank if world > 1 else 0), n_threads=max(1, 16 // max(1, min(world, 8))))
     n_bytes = host.size
     dev = torch.from_numpy(host).cuda()                 # resident in HBM before the timed region
@@ -102,7 +112,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -158,7 +168,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orc                             # checker / baseline only
         n_cpu = min(args.cpu_reads, args.reads)
-        sample = host[: n_cpu * (L + 1)]
+        sample = host[: n_cpu * (L + 1)] if args.read_len_max <= L else host
         o = orc.Oracle(k)
         t1 = time.perf_counter()
         o.scan_stream(sample, m)

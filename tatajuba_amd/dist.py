@@ -23,6 +23,9 @@ def all_gatherv_bytes(local, dist, group=None):
     """all-gatherv of a 1-D uint8 tensor: sizes first, then one padded all_gather (xGMI is point-to-point, the payloads
     are MB-scale: one collective on max-padded blocks beats a ring of sends).  Returns (list of tensors, sizes)."""
     world = dist.get_world_size(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":        # rehearsal on a one-GPU box: gloo gathers on the host
+        parts, sizes = all_gatherv_bytes(local.cpu(), dist, group)
+        return [p.to(local.device) for p in parts], sizes
     n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
