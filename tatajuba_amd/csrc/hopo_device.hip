@@ -380,15 +380,16 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     const u32 tpar = (u32) ((tile / gridDim.x) & 1);
     if (tid == 0) { T.ncand = 0; T.odd[tpar ^ 1u] = 0; }
     if (tid < 4) { T.code[G::CODEW - 4 + tid] = 0; T.start[G::MASKW - 4 + tid] = 0; T.sent[G::MASKW - 4 + tid] = 0xFFFFFFFFu; T.inval[G::MASKW - 4 + tid] = 0; }
+    const bool interior = (g0 >= 0) && (g0 + (long) G::WIN <= n_bytes);   // whole window inside the stream (uniform)
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's chunks of the tile have landed in raw
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
       const int c = tid + i * BLOCK;
       if (c < G::NCHUNK) {
         uint4 v = raw[c];
-        {
+        if (!interior) {
           const long g = g0 + 16l * c;
-          if (__builtin_expect (!((g >= 0) && (g + 16 <= n_bytes)), 0)) {
+          if (!((g >= 0) && (g + 16 <= n_bytes))) {
             const EdgeChunk e = edge_chunk (seq, n_bytes, g);
             v.x = e.x; v.y = e.y; v.z = e.z; v.w = e.w;
           }
@@ -1282,8 +1283,8 @@ __device__ __forceinline__ u32 key_digit (u64 c0, u64 c1, u64 meta, int pass, in
 
 __host__ int key_passes (int k) { return (13 + 4 * k + 7) / 8; }
 
-#define RS_ITEMS      4096
-#define RS_WAVE_ITEMS 1024
+#define RS_ITEMS      1024           // per workgroup: the sort only ever sees the kept set (1e5..1e6 records), so favour many small blocks
+#define RS_WAVE_ITEMS 256
 
 // lanes of the wavefront holding the same 8-bit digit as this lane
 __device__ __forceinline__ u64 match_digit (u32 d, bool active)
