@@ -79,6 +79,7 @@ struct TileLds
   unsigned short cand[MAXCAND];
   unsigned short fl[NCHUNK + 4];                         // per chunk: first byte | last byte << 8
   u32 ncand;
+  u32 grp[2];                                            // first tile of the current / next group of this workgroup
   u32 odd[2];                                            // per tile parity: some byte of the tile is neither ACGT nor '\n'
 };
 
@@ -90,7 +91,11 @@ struct DevCounters
   u64 n_null;       // padding records written into the buckets (reserved slots that stayed empty)
   u32 overflow;     // output list / a bucket too small
   u32 fix_overflow; // fix list too small
+  u32 work;         // next unassigned tile (workgroups take groups of TJ_TILE_GROUP tiles)
+  u32 pad;
 };
+
+#define TJ_TILE_GROUP 16
 
 struct FixEntry { long long pos; long long len; };
 
@@ -360,9 +365,13 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
   const u64 km = kmask (k);
   const u64 kbits = (1ull << k) - 1ull;                 // k <= 32
 
-  long tile = blockIdx.x;
-  if (tid == 0) { T.odd[0] = 0; T.odd[1] = 0; }
+  // Tiles are handed out dynamically in groups of TJ_TILE_GROUP (one global atomic per group): workgroups differ in
+  // how many tracts their tiles hold, and a static split leaves the slow ones running alone at the end.
+  if (tid == 0) { T.odd[0] = 0; T.odd[1] = 0; T.grp[0] = atomicAdd (&ctr->work, (u32) TJ_TILE_GROUP); }
   lds_barrier ();
+  long tile = (long) T.grp[0];
+  long grp_end = tile + TJ_TILE_GROUP;
+  u32 gpar = 0, it = 0;
   if (tile < n_tiles) {
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
@@ -372,12 +381,13 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
   }
 
   STAMP_DECL;
-  for (; tile < n_tiles; tile += gridDim.x) {
+  while (tile < n_tiles) {
     STAMP (0);
+    if (tid == 0 && tile + TJ_TILE_GROUP == grp_end) T.grp[gpar ^ 1u] = atomicAdd (&ctr->work, (u32) TJ_TILE_GROUP);  // first tile of a group: reserve the next
     const long g0 = tile * (long) TILE - TJ_HL;         // stream position of window byte 0 (may be negative)
 
     // ---- phase 1: classify the prefetched chunks into LDS, then prefetch the next tile ------------------------
-    const u32 tpar = (u32) ((tile / gridDim.x) & 1);
+    const u32 tpar = it & 1u;
     if (tid == 0) { T.ncand = 0; T.odd[tpar ^ 1u] = 0; }
     if (tid < 4) { T.code[G::CODEW - 4 + tid] = 0; T.start[G::MASKW - 4 + tid] = 0; T.sent[G::MASKW - 4 + tid] = 0xFFFFFFFFu; T.inval[G::MASKW - 4 + tid] = 0; }
     const bool interior = (g0 >= 0) && (g0 + (long) G::WIN <= n_bytes);   // whole window inside the stream (uniform)
@@ -426,8 +436,9 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     }
     sink.tick ();
     STAMP (1);
+    // the tile after this one: the next of the group, or the first of the next group (reserved TJ_TILE_GROUP - 1 tiles ago)
+    const long nt = (tile + 1 < grp_end) ? tile + 1 : (long) T.grp[gpar ^ 1u];
     {
-      const long nt = tile + gridDim.x;
       if (nt < n_tiles) {
 #pragma unroll
         for (int i = 0; i < G::NLOAD; i++) {
@@ -566,6 +577,9 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     }
     lds_barrier ();
     STAMP (8);
+    if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + TJ_TILE_GROUP; }
+    tile = nt;
+    it++;
   }
   STAMP_FLUSH;
 }
@@ -690,7 +704,7 @@ __device__ __forceinline__ u32 bucket_of_key (u64 c0, u64 c1, u32 base, u32 len1
 
 #define TJ_P        256                 // hash buckets
 #define TJ_PBITS    8
-#define TJ_STAGE_WORDS 4096             // 64-bit words of records a workgroup stages in LDS between partition passes
+#define TJ_STAGE_WORDS 2048             // 64-bit words of records a workgroup stages in LDS between partition passes
 #define TJ_CH0      1536                // chunk size unit in records; chunks are TJ_CH0 << ch_shift with ch_shift >= 2
 #define TJ_EMPTY    0xFFFFFFFFu
 
@@ -912,7 +926,7 @@ struct StageSink
 #define TJ_SB_WG_PER_CU 3               // grid = 3 workgroups per CU: 2 are resident (65 KB of LDS each), the queued third evens out the tail
 
 template <int W>
-__global__ __launch_bounds__ (TJ_SB_BLOCK)
+__global__ __launch_bounds__ (TJ_SB_BLOCK, 6)
 void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
                        Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
 {
@@ -1807,6 +1821,7 @@ extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t
   const uint8_t *seq = (const uint8_t *) d_stream;
   const Buckets BK = make_buckets (c);
   FixEntry *fix = (FixEntry *) c->fix.p;
+  HIPCHK (hipMemsetAsync (&c->d_ctr->work, 0, sizeof (u32), c->stream));
   HIPCHK (hipEventRecord (c->ev_s0, c->stream));
   switch (c->W) {
     case 1:
