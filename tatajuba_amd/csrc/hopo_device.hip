@@ -651,7 +651,8 @@ __global__ void nrun_fixup_list_kernel (const uint8_t *__restrict__ seq, long n_
 // ---- compact raw records and their hash ---------------------------------------------------------------------------
 // Between the scan and the aggregation a raw tract is W 64-bit words, W chosen from k so that nothing is wasted:
 //   W = 1 (k <= 12): flag | len << 2 | ctx1 << 12 | ctx0 << (12 + 2k) | base << (12 + 4k)          (<= 61 bits)
-//   W = 2 (k <= 28): { ctx0 | len[7:0] << 56 ,  ctx1 | (len[9:8] | flag << 2 | base << 4) << 56 }
+//   W = 2 (k <= 28): { 1 | base << 1 | len[4:0] << 2 | ctx0 << 7 ,  ctx1 | len[9:5] << 56 | flag << 61 }
+//                    (word 0 is never 0 and never uses bit 63: the aggregation claims table slots with it)
 //   W = 4          : { ctx0, ctx1, base | len << 2 | flag << 12, 0 }   (k > 28; padded so that 4 records fill a 128-byte line)
 // flag == 3 never occurs in a raw record (one tract, one strand): it marks a padding ("null") record.
 
@@ -659,7 +660,7 @@ template <int W> __device__ __forceinline__ void pack_raw (u64 c0, u64 c1, u32 b
 template <> __device__ __forceinline__ void pack_raw<1> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
 { w[0] = (u64) flag | ((u64) len10 << 2) | (c1 << 12) | (c0 << (12 + 2 * k)) | ((u64) base << (12 + 4 * k)); }
 template <> __device__ __forceinline__ void pack_raw<2> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
-{ w[0] = c0 | ((u64) (len10 & 0xFFu) << 56); w[1] = c1 | ((u64) ((len10 >> 8) | (flag << 2) | (base << 4)) << 56); }
+{ w[0] = 1ull | ((u64) base << 1) | ((u64) (len10 & 31u) << 2) | (c0 << 7); w[1] = c1 | ((u64) (len10 >> 5) << 56) | ((u64) flag << 61); }
 template <> __device__ __forceinline__ void pack_raw<4> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
 { w[0] = c0; w[1] = c1; w[2] = (u64) base | ((u64) len10 << 2) | ((u64) flag << 12); w[3] = 0; }
 template <int W> __device__ __forceinline__ void pack_null (u64 *w) { pack_raw<W> (0, 0, 0, 0, 3u, 2, w); }
@@ -673,8 +674,8 @@ template <> __device__ __forceinline__ void unpack_raw<1> (const u64 *w, int k, 
 template <> __device__ __forceinline__ void unpack_raw<2> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
 {
   const u64 m56 = (1ull << 56) - 1ull;
-  const u32 hi = (u32) (w[1] >> 56);
-  c0 = w[0] & m56; c1 = w[1] & m56; len10 = (u32) (w[0] >> 56) | ((hi & 3u) << 8); flag = (hi >> 2) & 3u; base = (hi >> 4) & 1u;
+  c0 = (w[0] >> 7) & m56; c1 = w[1] & m56;
+  base = (u32) (w[0] >> 1) & 1u; len10 = ((u32) (w[0] >> 2) & 31u) | (((u32) (w[1] >> 56) & 31u) << 5); flag = (u32) (w[1] >> 61) & 3u;
 }
 template <> __device__ __forceinline__ void unpack_raw<4> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
 { c0 = w[0]; c1 = w[1]; base = (u32) (w[2] & 3ull); len10 = (u32) ((w[2] >> 2) & 0x3FFull); flag = (u32) ((w[2] >> 12) & 3ull); }
@@ -1005,7 +1006,7 @@ __global__ void table_relayout_kernel (const u32 *__restrict__ old, u32 old_maxj
 // entirely in one round, so rounds never split a count.
 
 #define AG_S        4096                // table slots
-#define AG_CLOSE_AT 1792                // stop admitting new keys beyond this many (the count is one batch stale: up to 2048 more)
+#define AG_CLOSE_AT 1280                // stop admitting new keys beyond this many (one more batch may add 1024): load stays < 60 %
 #define AG_BLOCK    1024
 
 struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow; };
@@ -1056,7 +1057,7 @@ __device__ __forceinline__ bool agg_insert (AggLds &L, u64 c0, u64 c1, u32 k2, u
 // ---- W = 1 (k <= 12): the whole reduction key is the record word without its strand flag, so one 64-bit LDS
 // compare-and-swap per probe decides "new key / same key / other key" -- no tag, no publish step, no key read-back.
 #define AG1_S        8192
-#define AG1_CLOSE_AT 5632                // the count is one batch stale: up to 2048 more may be claimed
+#define AG1_CLOSE_AT 3584                // one more batch may add 1024 keys: the table stays below 60 % full (short probe chains)
 
 struct Agg1Lds
 {
@@ -1082,7 +1083,7 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
 
     u64 wn = 0;
     bool vn = false;
-    u32 cj = TJ_EMPTY, cc = TJ_NOCHUNK;
+    u32 cj = TJ_EMPTY, cc = TJ_NOCHUNK, oj = TJ_EMPTY, oc = TJ_NOCHUNK;
     auto fetch = [&] (u32 idx) {
       vn = false;
       if (idx < n) {
@@ -1094,10 +1095,15 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
     fetch ((u32) tid);
     u32 par = 0;
     for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK, par ^= 1u) {
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's record has arrived (fetched one batch ago)
       const u64 w = wn;
       const bool valid = vn;
       fetch (b0 + AG_BLOCK + tid);
-      if (tid == 0) L.closed[par ^ 1u] = (L.n_claimed > AG1_CLOSE_AT) ? 1u : 0u;
+      // Two barriers per batch.  (1) Every lane holds its record of this batch in registers and the key count of the
+      // previous batches is final: thread 0's decision is exact and leftovers (written below the records consumed so
+      // far) can never land on a record somebody still has to read.  (2) at the end: all inserts of the batch are done.
+      if (tid == 0) L.closed[par] = (L.n_claimed > AG1_CLOSE_AT) ? 1u : 0u;
+      lds_barrier ();
       const bool closed = L.closed[par] != 0u;
       if (valid && (w & 3ull) != 3ull) {
         const u64 key = w >> 2;
@@ -1116,10 +1122,11 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
           else if (old == 0ull) break;                  // closed table, key absent
           else slot = (slot + 1u) & (AG1_S - 1);
         }
-        if (!done) {
+        if (!done) {                                    // back to the front of the bucket (chunk id cached per lane)
           const u32 o = atomicAdd (&L.n_ovf, 1u);
-          const u64 at = bucket_slot (BK, bkt, o, false, nullptr);
-          if (at != ~0ull) BK.pool[at] = w;
+          const u32 j = chunk_of_pos (BK, o);
+          if (j != oj) { oj = j; oc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
+          if (oc != TJ_NOCHUNK) BK.pool[(((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift))] = w;
         }
       }
       lds_barrier ();
@@ -1170,6 +1177,147 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
   }
 }
 
+// ---- W = 2 (k <= 28): word 0 of the record is never 0 and leaves bit 63 free, so it doubles as the slot's claim word:
+// compare-and-swap 0 -> (word0 | PENDING), write word 1, then store word0 (release).  A prober that meets its own
+// word0 with PENDING set looks again; with it clear the second word is there to compare.
+#define AG2_S        4096
+#define AG2_CLOSE_AT 1280                // + 1024 of the batch in flight: below 60 % full
+#define AG2_PENDING  (1ull << 63)
+
+struct Agg2Lds
+{
+  u64 k0[AG2_S], k1[AG2_S];
+  u32 cf[AG2_S], cr[AG2_S];
+  u32 n_claimed, n_ovf, closed[2], total;
+  u32 wsum[AG_BLOCK / 64];
+};
+
+__global__ __launch_bounds__ (AG_BLOCK)
+void aggregate2_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+{
+  __shared__ Agg2Lds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 bkt = blockIdx.x;
+  u32 n = BK.cursors[bkt];
+  const u64 m56 = (1ull << 56) - 1ull, fmask = ~(3ull << 61);
+
+  while (n > 0) {
+    for (int i = tid; i < AG2_S; i += AG_BLOCK) { L.k0[i] = 0; L.cf[i] = 0; L.cr[i] = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.closed[0] = L.closed[1] = 0; }
+    __syncthreads ();
+
+    u64 wn0 = 0, wn1 = 0;
+    bool vn = false;
+    u32 cj = TJ_EMPTY, cc = TJ_NOCHUNK, oj = TJ_EMPTY, oc = TJ_NOCHUNK;
+    auto fetch = [&] (u32 idx) {
+      vn = false;
+      if (idx < n) {
+        const u32 j = chunk_of_pos (BK, idx);
+        if (j != cj) { cj = j; cc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
+        if (cc != TJ_NOCHUNK) {
+          const u64 at = (((u64) cc * TJ_CH0) << BK.ch_shift) + (idx - ((j * TJ_CH0) << BK.ch_shift));
+          vn = true; wn0 = BK.pool[2 * at]; wn1 = BK.pool[2 * at + 1];
+        }
+      }
+    };
+    fetch ((u32) tid);
+    u32 par = 0;
+    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK, par ^= 1u) {
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's record has arrived (fetched one batch ago)
+      const u64 w0 = wn0, w1 = wn1;
+      const bool valid = vn;
+      fetch (b0 + AG_BLOCK + tid);
+      // two barriers per batch: see aggregate1_kernel
+      if (tid == 0) L.closed[par] = (L.n_claimed > AG2_CLOSE_AT) ? 1u : 0u;
+      lds_barrier ();
+      const bool closed = L.closed[par] != 0u;
+      if (valid && ((w1 >> 61) & 3ull) != 3ull) {
+        const u64 key1 = w1 & fmask;
+        u32 h = (u32) w0 ^ __builtin_amdgcn_alignbit ((u32) (w0 >> 32), (u32) (w0 >> 32), 19) ^
+                __builtin_amdgcn_alignbit ((u32) key1, (u32) key1, 11) ^ __builtin_amdgcn_alignbit ((u32) (key1 >> 32), (u32) (key1 >> 32), 25);
+        h *= 0x9E3779B1u; h ^= h >> 15;
+        u32 slot = h & (AG2_S - 1);
+        bool done = false;
+        for (u32 probes = 0; probes < AG2_S && !done;) {
+          u64 old;
+          if (!closed) {
+            unsigned long long expected = 0ull;
+            __hip_atomic_compare_exchange_strong ((unsigned long long *) &L.k0[slot], &expected, (unsigned long long) (w0 | AG2_PENDING),
+                                                  __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = expected;
+            if (old == 0ull) {                          // claimed: publish the second word, then the first
+              L.k1[slot] = key1;
+              atomicAdd (&L.n_claimed, 1u);
+              __hip_atomic_store ((unsigned long long *) &L.k0[slot], (unsigned long long) w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+              atomicAdd ((w1 >> 62) & 1ull ? &L.cr[slot] : &L.cf[slot], 1u);
+              done = true;
+              break;
+            }
+            if (old == (w0 | AG2_PENDING)) continue;    // same first word, owner still writing: look again
+          }
+          else old = __hip_atomic_load ((unsigned long long *) &L.k0[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (old == w0 && L.k1[slot] == key1) { atomicAdd ((w1 >> 62) & 1ull ? &L.cr[slot] : &L.cf[slot], 1u); done = true; break; }
+          if (old == 0ull) break;                       // closed table, key absent
+          slot = (slot + 1u) & (AG2_S - 1);
+          probes++;
+        }
+        if (!done) {                                    // back to the front of the bucket (chunk id cached per lane)
+          const u32 o = atomicAdd (&L.n_ovf, 1u);
+          const u32 j = chunk_of_pos (BK, o);
+          if (j != oj) { oj = j; oc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
+          if (oc != TJ_NOCHUNK) {
+            const u64 at = (((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift));
+            BK.pool[2 * at] = w0; BK.pool[2 * at + 1] = w1;
+          }
+        }
+      }
+      lds_barrier ();
+    }
+    __syncthreads ();
+
+    u32 mine = 0;
+    u64 metas[AG2_S / AG_BLOCK];
+#pragma unroll
+    for (int r = 0; r < AG2_S / AG_BLOCK; r++) {
+      const int slot = tid + r * AG_BLOCK;
+      metas[r] = 0;
+      if (L.k0[slot]) {
+        const u32 cf = L.cf[slot], cr = L.cr[slot];
+        const u64 flag = (cf ? 1ull : 0ull) | (cr ? 2ull : 0ull);
+        const u64 cnt = ((u64) cf + (u64) cr) & 0xFFFFFull;
+        const int scnt = (cnt & 0x80000ull) ? (int) cnt - 0x100000 : (int) cnt;
+        if (remove_biased ? (flag == 3ull) : (scnt > 1)) {
+          const u64 a = L.k0[slot], b = L.k1[slot];
+          const u64 len10 = ((a >> 2) & 31ull) | (((b >> 56) & 31ull) << 5);
+          metas[r] = ((a >> 1) & 1ull) | (len10 << TJ_META_LEN_SHIFT) | (cnt << TJ_META_COUNT_SHIFT) |
+                     (0xffeull << TJ_META_MISM_SHIFT) | (flag << TJ_META_FLAG_SHIFT);
+          mine++;
+        }
+      }
+    }
+    const u32 x = wave_inclusive_scan (mine);
+    if (lane == 63) L.wsum[wave] = x;
+    __syncthreads ();
+    u32 wbase = 0, total = 0;
+    for (int wv = 0; wv < AG_BLOCK / 64; wv++) { const u32 sm = L.wsum[wv]; if (wv < wave) wbase += sm; total += sm; }
+    if (tid == 0) L.total = total ? atomicAdd (&fin->n_kept, total) : 0u;
+    __syncthreads ();
+    u64 at = (u64) L.total + wbase + x - mine;
+#pragma unroll
+    for (int r = 0; r < AG2_S / AG_BLOCK; r++)
+      if (metas[r]) {
+        const int slot = tid + r * AG_BLOCK;
+        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (L.k0[slot] >> 7) & m56; q[1] = L.k1[slot] & m56; q[2] = metas[r]; }
+        else fin->overflow = 1u;
+        at++;
+      }
+    __threadfence_block ();
+    __syncthreads ();
+    n = L.n_ovf;
+    __syncthreads ();
+  }
+}
+
 template <int W>
 __global__ __launch_bounds__ (AG_BLOCK)
 void aggregate_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
@@ -1203,15 +1351,16 @@ void aggregate_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ k
     fetch ((u32) tid);
     u32 par = 0;
     for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK, par ^= 1u) {
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's record has arrived (fetched one batch ago)
       u64 w[W];
 #pragma unroll
       for (int j = 0; j < W; j++) w[j] = wn[j];
       const bool valid = vn;
       fetch (b0 + AG_BLOCK + tid);                      // leftovers are written below b0 + AG_BLOCK: never where this reads
-      // One barrier per batch.  Thread 0 decides here whether the NEXT batch may still admit keys; the count it sees
-      // may miss the claims other waves are still making in the previous batch and all of this one (<= 2048).
-      if (tid == 0) L.closed[par ^ 1u] = (L.n_claimed > AG_CLOSE_AT) ? 1u : 0u;
-      const bool closed = L.closed[par] != 0u;          // decided during the previous batch, stable since its barrier
+      // two barriers per batch: see aggregate1_kernel
+      if (tid == 0) L.closed[par] = (L.n_claimed > AG_CLOSE_AT) ? 1u : 0u;
+      lds_barrier ();
+      const bool closed = L.closed[par] != 0u;
       if (valid) {
         u64 c0, c1; u32 base, len10, flag;
         unpack_raw<W> (w, k, c0, c1, base, len10, flag);
@@ -1901,6 +2050,14 @@ extern "C" long tjamd_raw_count (tjamd_counter *c)
   return rc ? -rc : c->n_raw_known;
 }
 
+// diagnostic: records per hash bucket after a synchronisation (not part of the public header)
+extern "C" long tjamd_debug_bucket_counts (tjamd_counter *c, unsigned *out, int n)
+{
+  if (tjamd_raw_count (c) < 0) return -1;
+  for (int b = 0; b < n && b < TJ_P; b++) out[b] = c->h_cursors[b];
+  return TJ_P;
+}
+
 extern "C" long tjamd_undefined_runs (tjamd_counter *c)
 {
   if (tjamd_raw_count (c) < 0) return -1;
@@ -2022,7 +2179,7 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   const Buckets BK = make_buckets (c);
   switch (c->W) {
     case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
-    case 2: hipLaunchKernelGGL (aggregate_kernel<2>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
+    case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
     default: hipLaunchKernelGGL (aggregate_kernel<4>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
   }
   HIPCHK (hipGetLastError ());
