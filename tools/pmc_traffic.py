@@ -24,7 +24,7 @@ write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"_note": __doc__.split("\n\n")[1].replace("\n", " ")}
 for k in sorted(set(fetch) | set(write)):
     short = k.split("(")[0].replace("void ", "")
-    if not any(s in short for s in ("scan_bins", "aggregate", "radix_scatter")):
+    if not any(s in short for s in ("scan_bins", "aggregate", "radix_scatter", "aggregate1", "aggregate2")):
         continue
     f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
     corr = 2.0 if "scan_bins" in short else 1.0
