@@ -141,10 +141,9 @@ __device__ __forceinline__ void classify_word_fast (u32 x, u32 prev_word, u32 &c
   // delimiter: the only byte of the fast path without bit 6
   const u32 s = (~x >> 6) & 0x01010101u;
   sent4 = __builtin_amdgcn_udot4 (s, 0x08040201u, 0u, false);
-  // validation: every byte must be the letter its code stands for, or '\n' where bit 6 is clear
-  const u32 expect = __builtin_amdgcn_perm (0u, 0x54474341u, c);      // 'A','C','G','T' indexed by the code
-  const u32 m = (s << 8) - s;                                        // 0xff per delimiter candidate
-  bad = (m & (x ^ 0x0A0A0A0Au)) | (~m & (x ^ expect));
+  // validation: every byte must be the letter its code stands for, or '\n' where bit 6 is clear -- one 8-entry byte
+  // table look-up (v_perm_b32): entries 0..3 = 'A','C','G','T' by code, entries 4..7 = '\n'
+  bad = x ^ __builtin_amdgcn_perm (0x0A0A0A0Au, 0x54474341u, c | (s << 2));
   // run start: byte differs from its predecessor
   const u32 d = x ^ __builtin_amdgcn_alignbit (x, prev_word, 24);
   const u32 nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) >> 7) & 0x01010101u;
