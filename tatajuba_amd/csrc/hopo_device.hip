@@ -2245,7 +2245,7 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   hipLaunchKernelGGL (set_int_kernel, dim3 (1), dim3 (1), 0, c->stream, &c->d_fin->coverage, INT_MIN);
   hipLaunchKernelGGL (cov_insert_kernel, dim3 (grid_for (2 * n1)), dim3 (256), 0, c->stream, kept, n1, (u32 *) c->cov_keys.p, (int *) c->cov_sums.p, log2t);
   HIPCHK (hipGetLastError ());
-  hipLaunchKernelGGL (cov_max_kernel, dim3 (grid_for (t)), dim3 (256), 0, c->stream, (const u32 *) c->cov_keys.p, (const int *) c->cov_sums.p, t, &c->d_fin->coverage);
+  hipLaunchKernelGGL (cov_max_kernel, dim3 (std::min<unsigned> (grid_for (t), 256u)), dim3 (256), 0, c->stream, (const u32 *) c->cov_keys.p, (const int *) c->cov_sums.p, t, &c->d_fin->coverage);
   HIPCHK (hipGetLastError ());
   HIPCHK (hipEventRecord (c->ev_f1, c->stream));
   c->fin_timed = true;
