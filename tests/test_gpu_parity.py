@@ -328,6 +328,35 @@ def test_dropin_large_file_batches(tmp_path):
     h.delete()
 
 
+@pytest.mark.parametrize("k,m", [(2, 1), (10, 3), (25, 4)])
+def test_many_small_batches_grow_the_bucket_storage(k, m):
+    """one counter, hundreds of small scans: the chunk pool and the chunk tables have to grow (and keep what is there)
+    again and again; k = 2 piles everything into a few buckets"""
+    rng = np.random.default_rng(11)
+    c = tj.Counter(k)
+    o = orc.Oracle(k)
+    for i in range(150):
+        n = int(rng.integers(50, 3000))
+        s = tj.synth_stream(n, int(rng.integers(40, 200)), 30000, seed_reads=1000 + i)
+        c.scan_host(s, m)
+        o.scan_stream(s, m)
+        if i % 37 == 0:
+            assert c.raw_count() == o.c.n_elem          # synchronise now and then (tightens the bounds)
+    big = tj.synth_stream(400000, 150, 30000, seed_reads=77)   # then one batch far larger than everything before
+    c.scan_host(big, m)
+    o.scan_stream(big, m)
+    got = c.download_raw()
+    exp = as_records(o.elems())
+    assert len(got) == len(exp) and (rec_sorted(got) == rec_sorted(exp)).all()
+    st = c.finalise(1, 3)
+    o.finalise(1, 3)
+    assert st == o.c.status == 0 and c.download_kept().tobytes() == o.elems().tobytes() and c.coverage == o.c.coverage
+    # the counter is reusable after finalise
+    c.scan_host(big, m)
+    assert c.raw_count() == len(as_records(oracle_raw(big, k, m).elems()))
+    c.close()
+
+
 def test_merge_samples_device():
     """cross-sample merge on the GPU == the numpy union (tatajuba_amd/dist.py), counts per sample and key order"""
     torch = pytest.importorskip("torch")
