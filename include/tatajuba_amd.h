@@ -53,7 +53,8 @@ int  tjamd_counter_device (const tjamd_counter *c);
 int  tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t n_bytes, int min_tract_size);
 /* Same from host memory (copied to HBM first). */
 int  tjamd_scan_host (tjamd_counter *c, const void *h_stream, size_t n_bytes, int min_tract_size);
-/* Located variant: records go to a separate list with positions, sorted by position (emission order) on download. */
+/* Located variant: records go to a separate list with positions, sorted by position (emission order) on download.
+ * min_tract_size == 0 selects the all-monomers scan (reference: src/hopo_counter.c:260-283). */
 long tjamd_scan_host_located (tjamd_counter *c, const void *h_stream, size_t n_bytes, int min_tract_size,
                               tjamd_located_record *out, long capacity);
 

@@ -98,6 +98,10 @@ hopo_counter new_or_append_hopo_counter_from_file (hopo_counter hc, const char *
  * host array hc->elem (so hc->elem[0..n_elem) is readable right after the call, as callers expect). */
 void update_hopo_counter_from_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size);
 
+/* reference: src/hopo_counter.h:73, src/hopo_counter.c:260-283; called at src/genome_set.c:543.  Same as above for every
+ * base that differs from both of its neighbours (tract length 1), used when a reference window holds no tract. */
+void update_hopo_counter_from_seq_all_monomers (hopo_counter hc, char *seq, int seq_length);
+
 /* reference: src/hopo_counter.h:78, src/hopo_counter.c:339-417.  Device radix sort + segmented reduce of the raw
  * records, strand-bias/singleton filter, per-context depth index and coverage estimate; leaves elem, n_elem, n_alloc,
  * idx_initial, idx_final, n_idx, coverage, ref_start exactly as the reference has them when it reaches its BWA step

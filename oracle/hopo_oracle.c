@@ -119,6 +119,32 @@ orc_scan_seq (orc_counter *oc, const char *seq, int L, int m)
   }
 }
 
+/* reference: src/hopo_counter.c:260-283.  Every base that differs from both neighbours ("monomer") with k bases on
+ * either side is recorded with length 1 (used when a reference window holds no tract: src/genome_set.c:543). */
+void
+orc_scan_seq_all_monomers (orc_counter *oc, const char *seq, int L)
+{
+  const uint8_t *s = (const uint8_t *) seq;
+  int k = oc->kmer_size, i, j, n;
+  uint8_t codes[64];
+  int base = 0, flag = 0, have_ctx = 0;
+  for (i = k; i < L - k; i++) {
+    if (s[i] == s[i - 1] || s[i] == s[i + 1]) continue;
+    if (orc_fwd[s[i]] < orc_cmp[s[i]]) {
+      for (n = 0, j = i - k; j < i; j++) codes[n++] = orc_fwd[s[j]];
+      for (j = i + 1; j <= i + k; j++) codes[n++] = orc_fwd[s[j]];
+      base = orc_fwd[s[i]]; flag = 1; have_ctx = 1;
+    }
+    else if (orc_fwd[s[i]] > orc_cmp[s[i]]) {
+      for (n = 0, j = i + k; j > i; j--) codes[n++] = orc_cmp[s[j]];
+      for (j = i - 1; j >= i - k; j--) codes[n++] = orc_cmp[s[j]];
+      base = orc_cmp[s[i]]; flag = 2; have_ctx = 1;
+    }
+    if (have_ctx) orc_append (oc, codes, base, 1, i - k, flag);   /* unconditional in the reference (:280) */
+    else oc->n_undefined++;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* FASTA/FASTQ tokenizer -- reference: src/kseq.h:62-75 (getc), :89-129 (line reader), :172-212 (record reader) */
 

@@ -22,6 +22,7 @@ typedef struct
 orc_counter *orc_new (int kmer_size);
 void orc_free (orc_counter *oc);
 void orc_scan_seq (orc_counter *oc, const char *seq, int seq_length, int min_tract_size);
+void orc_scan_seq_all_monomers (orc_counter *oc, const char *seq, int seq_length);
 long orc_scan_file (orc_counter *oc, const char *path, int min_tract_size);        /* reads parsed, -1 = cannot open */
 long orc_scan_stream (orc_counter *oc, const char *buf, size_t n, int min_tract_size); /* '\n'-delimited reads */
 void orc_finalise (orc_counter *oc, int remove_biased, int min_coverage);

@@ -55,6 +55,7 @@ def lib():
         L.orc_new.restype = C.POINTER(_OrcCounter); L.orc_new.argtypes = [C.c_int]
         L.orc_free.argtypes = [C.POINTER(_OrcCounter)]
         L.orc_scan_seq.argtypes = [C.POINTER(_OrcCounter), C.c_char_p, C.c_int, C.c_int]
+        L.orc_scan_seq_all_monomers.argtypes = [C.POINTER(_OrcCounter), C.c_char_p, C.c_int]
         L.orc_scan_file.restype = C.c_long; L.orc_scan_file.argtypes = [C.POINTER(_OrcCounter), C.c_char_p, C.c_int]
         L.orc_scan_stream.restype = C.c_long
         L.orc_scan_stream.argtypes = [C.POINTER(_OrcCounter), C.c_void_p, C.c_size_t, C.c_int]
@@ -83,6 +84,11 @@ class Oracle:
         if isinstance(seq, str):
             seq = seq.encode("latin-1")
         lib().orc_scan_seq(self._p, seq, len(seq), m)
+
+    def scan_seq_all_monomers(self, seq):
+        if isinstance(seq, str):
+            seq = seq.encode("latin-1")
+        lib().orc_scan_seq_all_monomers(self._p, seq, len(seq))
 
     def scan_file(self, path, m):
         n = lib().orc_scan_file(self._p, os.fsencode(path), m)

@@ -73,6 +73,7 @@ _LIB = None
 # every symbol the two headers declare (checked by tests/test_cabi.py against the .so and the header text)
 EXPORTS = [
     "new_hopo_counter", "del_hopo_counter", "new_or_append_hopo_counter_from_file", "update_hopo_counter_from_seq",
+    "update_hopo_counter_from_seq_all_monomers",
     "finalise_hopo_counter", "compare_hopo_element_decreasing", "compare_hopo_context",
     "generate_name_from_flanking_contexts", "generate_tract_as_string", "print_tatajuba_options",
     "dna_in_2_bits", "bit_2_dna",
@@ -127,6 +128,8 @@ def lib():
     L.new_or_append_hopo_counter_from_file.argtypes = [P, C.c_char_p, Options]
     L.update_hopo_counter_from_seq.restype = None
     L.update_hopo_counter_from_seq.argtypes = [P, C.c_char_p, C.c_int, C.c_int]
+    L.update_hopo_counter_from_seq_all_monomers.restype = None
+    L.update_hopo_counter_from_seq_all_monomers.argtypes = [P, C.c_char_p, C.c_int]
     L.finalise_hopo_counter.restype = None; L.finalise_hopo_counter.argtypes = [P]
     L.generate_name_from_flanking_contexts.restype = C.c_void_p
     L.generate_name_from_flanking_contexts.argtypes = [C.POINTER(C.c_uint64), C.c_int8, C.c_int, C.c_bool]
@@ -342,6 +345,12 @@ class HopoCounter:
         if isinstance(seq, str):
             seq = seq.encode("latin-1")
         lib().update_hopo_counter_from_seq(self._p, seq, len(seq), min_tract_size)
+
+    # reference: update_hopo_counter_from_seq_all_monomers (src/hopo_counter.c:260)
+    def update_from_seq_all_monomers(self, seq):
+        if isinstance(seq, str):
+            seq = seq.encode("latin-1")
+        lib().update_hopo_counter_from_seq_all_monomers(self._p, seq, len(seq))
 
     # reference: finalise_hopo_counter (src/hopo_counter.c:339)
     def finalise(self):

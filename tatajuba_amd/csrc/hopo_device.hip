@@ -63,14 +63,15 @@ extern "C" int tjamd_device_count (void)
 #define TJ_HL      64                   // left halo  (>= max k + 1, multiple of 32)
 #define TJ_HR      192                  // right halo (tracts whose end + k stays inside are handled from LDS)
 
-template <int BLOCK, int TILE>
+template <int BLOCK, int TILE, int CANDDIV = 2>
 struct TileLds
 {
   static constexpr int WIN = TJ_HL + TILE + TJ_HR;       // bytes of stream seen by one tile
   static constexpr int NCHUNK = WIN / 16;                // 16-byte chunks
   static constexpr int MASKW = WIN / 32 + 4;             // words per bit-plane (+ zeroed pad for 3-word funnel reads)
   static constexpr int CODEW = WIN / 16 + 4;             // words of 2-bit codes (+ pad)
-  static constexpr int MAXCAND = TILE / 2;               // tracts have >= 2 bases: at most one candidate per 2 bytes
+  static constexpr int MAXCAND = TILE / CANDDIV;         // tracts have >= 2 bases: one candidate per 2 bytes at most
+                                                         // (CANDDIV 1: the located kernel's all-monomers mode)
   static constexpr int NLOAD = (NCHUNK + BLOCK - 1) / BLOCK;
   u32 code[CODEW];
   u32 start[MASKW];
@@ -355,11 +356,11 @@ __device__ __noinline__ EdgeChunk edge_chunk (const uint8_t *__restrict__ seq, l
 // by the lane that owns chunk c.  It must be a __shared__ variable of its own: the compiler orders every later LDS access
 // that MAY alias an in-flight LDS-DMA behind vmcnt(0), and members of one struct all may alias -- as part of TileLds the
 // "prefetch" was waited for at the first LDS instruction after its issue.
-template <int BLOCK, int TILE, class Sink>
+template <int BLOCK, int TILE, int CANDDIV, class Sink>
 __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
-                                            TileLds<BLOCK, TILE> &T, uint4 *raw, Sink &sink, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
+                                            TileLds<BLOCK, TILE, CANDDIV> &T, uint4 *raw, Sink &sink, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
 {
-  typedef TileLds<BLOCK, TILE> G;
+  typedef TileLds<BLOCK, TILE, CANDDIV> G;
   const int tid = threadIdx.x;
   const u64 km = kmask (k);
   const u64 kbits = (1ull << k) - 1ull;                 // k <= 32
@@ -469,6 +470,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
         if ((T.fl[ch] & 0xFFu) != (u32) (T.fl[ch - 1] >> 8)) reinterpret_cast<unsigned short *> (T.start)[ch] |= 1;
       }
       u32 cand = (u32) S & 0xFFFFu;
+      if (mprime <= 0) cand &= (u32) (S >> 1);                      // monomer mode: the next position starts a run too
       for (int j = 1; j < mprime; j++) cand &= ~(u32) (S >> j);     // next m'-1 positions continue the run
       cand &= ~(u32) reinterpret_cast<unsigned short *> (T.sent)[p0 >> 4];  // a run of delimiters is not a tract
       // one LDS atomic per wavefront (512 same-address atomics serialise): exclusive prefix of the lane counts
@@ -594,7 +596,8 @@ __device__ bool stale_context (const uint8_t *__restrict__ seq, long n_bytes, lo
     const u32 b = seq[p];
     long q = p;
     while (q - 1 >= 0 && seq[q - 1] == b) q--;          // run [q, p]
-    if (byte_is_acgtu (b) && (p - q + 1) >= mprime) {
+    // a recorded tract: >= m' equal bases -- or, in monomer mode (mprime <= 0), exactly one
+    if (byte_is_acgtu (b) && (mprime > 0 ? (p - q + 1) >= mprime : p == q)) {
       u64 left, right; u32 linv, rinv;
       // recorded iff k bases of the same read precede it (its right side is fine: it ends before our run does);
       // an earlier run would start even closer to the read start, so the search stops here either way
@@ -625,10 +628,10 @@ __global__ __launch_bounds__ (256)
 void scan_list_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
                        u64 *__restrict__ out, u64 cap, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
 {
-  __shared__ TileLds<256, 4096> T;
-  __shared__ uint4 raw[TileLds<256, 4096>::NCHUNK];
+  __shared__ TileLds<256, 4096, 1> T;
+  __shared__ uint4 raw[TileLds<256, 4096, 1>::NCHUNK];
   ListSink sink = {out, cap, ctr};
-  scan_tiles<256, 4096> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap);
+  scan_tiles<256, 4096, 1> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap);
 }
 
 __global__ void nrun_fixup_list_kernel (const uint8_t *__restrict__ seq, long n_bytes, int k, int mprime,
@@ -935,7 +938,7 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
   __shared__ StageLds<W> SL;
   StageSink<W, TJ_SB_BLOCK> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
   sink.start ();
-  scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap);
+  scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE, 2> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap);
   sink.finish ();
 }
 
@@ -2008,13 +2011,13 @@ extern "C" int tjamd_scan_host (tjamd_counter *c, const void *h_stream, size_t n
 
 extern "C" long tjamd_scan_host_located (tjamd_counter *c, const void *h_stream, size_t n_bytes, int min_tract_size,
                                           tjamd_located_record *out, long capacity)
-{
-  int rc = check_scan_args (c, min_tract_size);
+{ // min_tract_size == 0: every isolated base instead of tracts (reference: update_hopo_counter_from_seq_all_monomers)
+  int rc = (min_tract_size == 0 && c) ? TJAMD_OK : check_scan_args (c, min_tract_size);
   if (rc) return -rc;
   if (n_bytes == 0) return 0;
   if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
-  const int mprime = std::max (min_tract_size, 2);
-  const long bound = (long) (n_bytes / (size_t) mprime) + 1;
+  const int mprime = min_tract_size == 0 ? 0 : std::max (min_tract_size, 2);
+  const long bound = (long) (n_bytes / (size_t) (mprime ? mprime : 1)) + 1;
   rc = ensure (c->stage, (n_bytes + 255) & ~(size_t) 255, c->stream);
   if (!rc) rc = ensure (c->loc, (size_t) bound * 32, c->stream);
   if (!rc) rc = ensure (c->fix, (size_t) TJ_FIX_CAP * sizeof (FixEntry), c->stream);

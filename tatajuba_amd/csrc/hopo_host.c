@@ -178,8 +178,23 @@ tjamd_read_file_stream (const char *path, unsigned char *out, long capacity, lon
 
 /* ---- one sequence, synchronously (reference: src/hopo_counter.c:219-258) ------------------------------------------ */
 
+static void tj_scan_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size);
+
 void
 update_hopo_counter_from_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size)
+{
+  tj_scan_seq (hc, seq, seq_length, min_tract_size < 1 ? 1 : min_tract_size);
+}
+
+/* reference: src/hopo_counter.c:260-283 */
+void
+update_hopo_counter_from_seq_all_monomers (hopo_counter hc, char *seq, int seq_length)
+{
+  tj_scan_seq (hc, seq, seq_length, 0);
+}
+
+static void
+tj_scan_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size)
 {
   tj_private *pv = tj_priv (hc);
   tjamd_counter *dev;
@@ -189,7 +204,7 @@ update_hopo_counter_from_seq (hopo_counter hc, char *seq, int seq_length, int mi
 
   if (seq_length <= hc->kmer_size) return;              /* reference loop bound :226 */
   dev = tj_device_counter (hc);
-  cap = seq_length / 2 + 2;
+  cap = (min_tract_size ? seq_length / 2 : seq_length) + 2;
   stream = (unsigned char *) malloc ((size_t) seq_length + 1);
   rec = (tjamd_located_record *) malloc ((size_t) cap * sizeof (tjamd_located_record));
   memcpy (stream, seq, (size_t) seq_length);

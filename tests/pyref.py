@@ -48,3 +48,28 @@ def scan_closed_form(seq, k, m):
                 out.append((last[0], n, s - k, last[1], last[2], last[3]))
         s = e + 1
     return out
+
+
+def scan_all_monomers(seq, k):
+    """reference: update_hopo_counter_from_seq_all_monomers (src/hopo_counter.c:260-283): every position k <= i < L-k
+    whose byte differs from both neighbours is recorded with length 1; a non-ACGTU byte re-uses the previous record's
+    context (or is dropped when there is none)."""
+    L = len(seq)
+    out = []
+    last = None
+    for i in range(k, L - k):
+        if seq[i] == seq[i - 1] or seq[i] == seq[i + 1]:
+            continue
+        ch = seq[i]
+        if ch in FWD:
+            left = seq[i - k:i]
+            right = seq[i + 1:i + 1 + k]
+            f = FWD[ch]
+            if f < 2:
+                last = (f, 1, pack([code(c) for c in left]), pack([code(c) for c in right]))
+            else:
+                last = (3 - f, 2, pack([code(c, True) for c in reversed(right)]),
+                        pack([code(c, True) for c in reversed(left)]))
+        if last is not None:
+            out.append((last[0], 1, i - k, last[1], last[2], last[3]))
+    return out

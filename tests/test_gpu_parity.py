@@ -118,6 +118,31 @@ def test_update_from_seq_appends_and_m2_rescan():
     h.delete()
 
 
+def test_update_from_seq_all_monomers():
+    # reference: update_hopo_counter_from_seq_all_monomers (src/hopo_counter.c:260-283; caller src/genome_set.c:543)
+    rng = random.Random(5)
+    for k in (2, 3, 10, 25, 32):
+        h = tj.HopoCounter.new(k)
+        o = orc.Oracle(k)
+        for it in range(12):
+            ab = ["ACGT", "ACGTN", "ACGTacgtUN-", "AT"][it % 4]
+            L = rng.choice([0, 5, 70, 300, 5000, 20000])
+            s = []
+            while len(s) < L:
+                s.extend(rng.choice(ab) * rng.choice([1, 1, 1, 1, 2, 3, 5]))
+            seq = "".join(s[:L])
+            if it == 7:
+                seq = "ACGT" * 3000               # a monomer at every position: one candidate per byte of a tile
+            h.update_from_seq_all_monomers(seq)
+            o.scan_seq_all_monomers(seq)
+            if it % 3 == 0:                       # tract and monomer rescans interleave in the reference's caller
+                h.update_from_seq(seq, 2)
+                o.scan_seq(seq, 2)
+        assert h.c.n_elem == o.c.n_elem > 1000, k
+        assert h.elems().tobytes() == o.elems().tobytes(), k
+        h.delete()
+
+
 # ---- random strings: located records in emission order, every alphabet quirk --------------------------------------
 
 def test_random_reads_located_order():

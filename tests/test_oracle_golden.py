@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import orc
-from tests.pyref import scan_closed_form
+from tests.pyref import scan_all_monomers, scan_closed_form
 
 
 def records_of(o, k):
@@ -131,6 +131,27 @@ def test_state_machine_equals_closed_form():
         o = orc.Oracle(k)
         o.scan_seq(seq, m)
         assert records_of(o, k) == scan_closed_form(seq, k, m), (seq, k, m)
+
+
+def test_all_monomers_equals_closed_form():
+    # reference: update_hopo_counter_from_seq_all_monomers (src/hopo_counter.c:260-283)
+    rng = random.Random(77)
+    alphabets = ["ACGT", "ACGTN", "ACGTacgtUN-", "AT"]
+    total = 0
+    for it in range(2000):
+        ab = alphabets[it % len(alphabets)]
+        L = rng.randint(0, 80)
+        s = []
+        while len(s) < L:
+            s.extend(rng.choice(ab) * rng.choice([1, 1, 1, 1, 2, 3, 5]))
+        seq = "".join(s[:L])
+        k = rng.choice([1, 2, 3, 4, 7, 10, 16, 25, 32])
+        o = orc.Oracle(k)
+        o.scan_seq_all_monomers(seq)
+        exp = scan_all_monomers(seq, k)
+        assert records_of(o, k) == exp, (seq, k)
+        total += len(exp)
+    assert total > 5000
 
 
 def test_stream_equals_per_read():
