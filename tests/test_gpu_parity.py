@@ -328,6 +328,49 @@ def test_dropin_mixed_host_and_device_records(tmp_path):
     h.delete()
 
 
+def test_dropin_one_thread_per_sample(tmp_path):
+    # the reference's caller is an OpenMP loop with one sample per thread (src/genome_set.c:66-94): six counters are
+    # filled, finalised and re-scanned concurrently on the one GPU (ctypes releases the GIL around every call)
+    import threading
+    jobs = []
+    for i in range(6):
+        k, m = [(10, 3), (25, 4), (32, 3)][i % 3]
+        s = tj.synth_stream(30000 + 4000 * i, 120 + 10 * i, 50000 + 1000 * i)
+        path = str(tmp_path / f"s{i}.fa")
+        with open(path, "wb") as fh:
+            fh.write(b"".join(b">r\n" + r + b"\n" for r in bytes(s).split(b"\n") if r))
+        jobs.append((path, k, m, s))
+    got, errs = [None] * len(jobs), []
+
+    def work(i):
+        try:
+            path, k, m, _ = jobs[i]
+            opt = tj.Options.defaults(k, m, 3, True, paired_end=True)
+            h = tj.HopoCounter.new_or_append_from_file(None, path, opt)
+            tj.HopoCounter.new_or_append_from_file(h, path, opt)
+            h.finalise()
+            w = tj.HopoCounter.new(k)
+            w.update_from_seq("ACGTTGCAAGGCTTTTTTAGGCATCGATCGGGATCGATTTAGCTAGCAAAACTAGCTAGCTAGGGGGCTAGCATCGATCGAT" * 3, 2)
+            got[i] = (h.c.n_elem, h.c.coverage, h.elems().tobytes(), w.elems().tobytes())
+            w.delete()
+            h.delete()
+        except Exception as e:                      # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for i, (path, k, m, s) in enumerate(jobs):
+        o = orc.Oracle(k)
+        o.scan_stream(s, m); o.scan_stream(s, m)
+        o.finalise(1, 3)
+        w = orc.Oracle(k)
+        w.scan_seq("ACGTTGCAAGGCTTTTTTAGGCATCGATCGGGATCGATTTAGCTAGCAAAACTAGCTAGCTAGGGGGCTAGCATCGATCGAT" * 3, 2)
+        assert got[i][0] == o.c.n_elem > 0 and got[i][1] == o.c.coverage, i
+        assert got[i][2] == o.elems().tobytes() and got[i][3] == w.elems().tobytes(), i
+
+
 def test_dropin_large_file_batches(tmp_path):
     # > 64 MiB of sequence so that the double-buffered batching is exercised
     s = tj.synth_stream(600000, 150, 2000000)
