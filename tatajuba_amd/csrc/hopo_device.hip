@@ -164,6 +164,9 @@ struct Stamper
   __device__ __forceinline__ void mark (int i) { unsigned long long t = __builtin_amdgcn_s_memtime (); acc[i] += t - last; last = t; }
   __device__ __forceinline__ void flush () { if (threadIdx.x == 0) for (int i = 0; i < 16; i++) atomicAdd (&tj_stamp_acc[i], acc[i]); }
 };
+#define ASTAMP_DECL unsigned long long a_last = __builtin_amdgcn_s_memtime (), a_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define ASTAMP(i) { unsigned long long t_ = __builtin_amdgcn_s_memtime (); a_acc[i] += t_ - a_last; a_last = t_; }
+#define ASTAMP_FLUSH if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd (&tj_stamp_acc[16 + i_], a_acc[i_])
 #define STAMP_DECL Stamper stamper; stamper.begin (); sink.stp = &stamper
 #define STAMP(i) stamper.mark (i)
 #define PSTAMP(i) stp->mark (i)
@@ -172,11 +175,14 @@ struct Stamper
 extern "C" int tjamd_debug_stamps (unsigned long long *out, int reset)
 {
   unsigned long long z[32] = {0};
-  if (hipMemcpyFromSymbol (out, HIP_SYMBOL (tj_stamp_acc), 16 * 8) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol (out, HIP_SYMBOL (tj_stamp_acc), 32 * 8) != hipSuccess) return 1;
   if (reset && hipMemcpyToSymbol (HIP_SYMBOL (tj_stamp_acc), z, 32 * 8) != hipSuccess) return 1;
   return 0;
 }
 #else
+#define ASTAMP_DECL
+#define ASTAMP(i)
+#define ASTAMP_FLUSH
 #define STAMP_DECL
 #define STAMP(i)
 #define PSTAMP(i)
@@ -1059,13 +1065,15 @@ __device__ __forceinline__ bool agg_insert (AggLds &L, u64 c0, u64 c1, u32 k2, u
 // ---- W = 1 (k <= 12): the whole reduction key is the record word without its strand flag, so one 64-bit LDS
 // compare-and-swap per probe decides "new key / same key / other key" -- no tag, no publish step, no key read-back.
 #define AG1_S        8192
-#define AG1_CLOSE_AT 3584                // one more batch may add 1024 keys: the table stays below 60 % full (short probe chains)
+#define AG1_CLOSE_AT 3584                // at most one more key per lane (1024) gets in: the table stays below 60 % full
+#define AG1_R        4                   // records in flight per lane
+#define AG1_MARK     (~0ull)             // a key is at most 59 bits
 
 struct Agg1Lds
 {
   u64 key[AG1_S];                       // record >> 2 (never 0: the stored length of a tract is >= 2)
-  u32 cf[AG1_S], cr[AG1_S];
-  u32 n_claimed, n_ovf, closed[2], total;
+  u32 cnt[2 * AG1_S];                   // per slot: records seen on the forward / on the reverse strand
+  u32 n_claimed, n_ovf, total;
   u32 wsum[AG_BLOCK / 64];
 };
 
@@ -1078,62 +1086,120 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
   u32 n = BK.cursors[bkt];
   const u64 km = kmask (k);
 
+  ASTAMP_DECL;
   while (n > 0) {
-    for (int i = tid; i < AG1_S; i += AG_BLOCK) { L.key[i] = 0; L.cf[i] = 0; L.cr[i] = 0; }
-    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.closed[0] = L.closed[1] = 0; }
+    ASTAMP (0);
+    for (int i = tid; i < AG1_S; i += AG_BLOCK) { L.key[i] = 0; L.cnt[2 * i] = 0; L.cnt[2 * i + 1] = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; }
     __syncthreads ();
 
-    u64 wn = 0;
-    bool vn = false;
+    // AG1_R records per lane are in flight while the previous AG1_R are inserted: with one 8-byte load per lane the
+    // kernel sat at latency x (8 KB per CU in flight) = 1.4 TB/s whatever the table did.
+    u64 wn[AG1_R];
+    u32 vn = 0;
     u32 cj = TJ_EMPTY, cc = TJ_NOCHUNK, oj = TJ_EMPTY, oc = TJ_NOCHUNK;
-    auto fetch = [&] (u32 idx) {
-      vn = false;
-      if (idx < n) {
-        const u32 j = chunk_of_pos (BK, idx);
-        if (j != cj) { cj = j; cc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
-        if (cc != TJ_NOCHUNK) { vn = true; wn = BK.pool[(((u64) cc * TJ_CH0) << BK.ch_shift) + (idx - ((j * TJ_CH0) << BK.ch_shift))]; }
+    auto fetch = [&] (u32 first) {
+      vn = 0;
+#pragma unroll
+      for (int r = 0; r < AG1_R; r++) {
+        const u32 idx = first + (u32) r * AG_BLOCK;
+        wn[r] = 0;
+        if (idx < n) {
+          const u32 j = chunk_of_pos (BK, idx);
+          if (j != cj) { cj = j; cc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
+          if (cc != TJ_NOCHUNK) { vn |= 1u << r; wn[r] = BK.pool[(((u64) cc * TJ_CH0) << BK.ch_shift) + (idx - ((j * TJ_CH0) << BK.ch_shift))]; }
+        }
       }
     };
     fetch ((u32) tid);
-    u32 par = 0;
-    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK, par ^= 1u) {
-      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's record has arrived (fetched one batch ago)
-      const u64 w = wn;
-      const bool valid = vn;
-      fetch (b0 + AG_BLOCK + tid);
-      // Two barriers per batch.  (1) Every lane holds its record of this batch in registers and the key count of the
-      // previous batches is final: thread 0's decision is exact and leftovers (written below the records consumed so
-      // far) can never land on a record somebody still has to read.  (2) at the end: all inserts of the batch are done.
-      if (tid == 0) L.closed[par] = (L.n_claimed > AG1_CLOSE_AT) ? 1u : 0u;
+    ASTAMP (1);
+    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK * AG1_R) {
+      // this round's records have arrived (fetched one round ago).  The registers pass through the asm so that the
+      // compiler stops tracking them as pending loads: otherwise it waits for them again at their first use -- after
+      // the next round's loads have been issued, i.e. for those as well (vmcnt counts in order).
+      asm volatile ("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]) :: "memory");
+      static_assert (AG1_R == 4, "asm operand list");
+      ASTAMP (2);
+      u64 w[AG1_R];
+#pragma unroll
+      for (int r = 0; r < AG1_R; r++) w[r] = wn[r];
+      const u32 valid = vn;
+      fetch (b0 + AG_BLOCK * AG1_R + tid);
+      ASTAMP (3);
+      // One barrier per round: every lane holds its records of this round in registers, so the leftovers written below
+      // (in place, from the front of the bucket: fewer than the records consumed so far) never land on a record
+      // somebody still has to read.  Closing the table needs no barrier: see the slot protocol.
       lds_barrier ();
-      const bool closed = L.closed[par] != 0u;
-      if (valid && (w & 3ull) != 3ull) {
-        const u64 key = w >> 2;
-        u32 h = (u32) key ^ __builtin_amdgcn_alignbit ((u32) (key >> 32), (u32) (key >> 32), 17);
-        h *= 0x9E3779B1u; h ^= h >> 15;
-        u32 slot = h & (AG1_S - 1);
-        bool done = false;
-        for (u32 probes = 0; probes < AG1_S && !done; probes++) {
-          u64 old;
-          if (!closed) {
-            old = atomicCAS ((unsigned long long *) &L.key[slot], 0ull, (unsigned long long) key);
-            if (old == 0ull) { atomicAdd (&L.n_claimed, 1u); old = key; }
+      ASTAMP (4);
+#if defined(TJ_EXP_AGG) && TJ_EXP_AGG == 1      // experiment: loads only
+      { u64 acc = 0;
+#pragma unroll
+        for (int r = 0; r < AG1_R; r++) acc ^= w[r];
+        if (acc == 0x123456789ull) atomicAdd (&L.n_ovf, 1u);
+        continue; }
+#endif
+      // Table protocol.  Slots come in aligned pairs read with one 16-byte LDS load; a key's probe chain is its home
+      // pair, the next pair, ... and it lives in the first slot of the chain that was free when it arrived.  Almost
+      // every record finds its key with that one load and adds to its counter (no compare-and-swap: a bucket holds
+      // each key hundreds of times).  A new key is CASed into the first free slot of the chain while the table is
+      // open; once it is closed (enough keys; a lane looks before each claim, so at most one more key per lane gets
+      // in) that slot is MARKed instead, and a MARK ends the chain for everybody: either the key or a MARK wins the
+      // slot, so a key is in the table for all of its records or for none (those go back to the bucket's front).
+      // Lanes work through their AG1_R records independently (a wave loops until all its lanes are through): the
+      // iterations of a wave follow the lane with the most probes in total, not the worst probe of every record.
+      {
+        u32 r = 0, probes = 0;
+        u64 cur = w[0];
+        auto home = [] (u64 key) {
+          u32 h = (u32) key ^ __builtin_amdgcn_alignbit ((u32) (key >> 32), (u32) (key >> 32), 17);
+          h *= 0x9E3779B1u; h ^= h >> 15;
+          return h & (AG1_S / 2 - 1);
+        };
+        u32 pair = home (cur >> 2);
+        while (r < AG1_R) {
+          bool adv = false, left = false;
+          if (!((valid >> r) & 1u) || (cur & 3ull) == 3ull) adv = true;
+          else {
+            const u64 key = cur >> 2;
+            const u32 strand = (u32) (cur >> 1) & 1u;
+            const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *> (&L.key[2 * pair]);
+            if (kk.x == key || kk.y == key) { atomicAdd (&L.cnt[4 * pair + (kk.x == key ? 0u : 2u) + strand], 1u); adv = true; }
+            else {
+              const bool e0 = (kk.x == 0ull) | (kk.x == AG1_MARK), e1 = (kk.y == 0ull) | (kk.y == AG1_MARK);
+              if (e0 | e1) {                            // the chain ends in this pair
+                const u32 slot = 2 * pair + (e0 ? 0u : 1u);
+                if ((e0 ? kk.x : kk.y) == AG1_MARK) { left = true; adv = true; }
+                else {
+                  const bool closed = __hip_atomic_load (&L.n_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > AG1_CLOSE_AT;
+                  const u64 old = atomicCAS ((unsigned long long *) &L.key[slot], 0ull, closed ? AG1_MARK : (unsigned long long) key);
+                  if (old == 0ull) {
+                    if (closed) left = true;
+                    else { atomicAdd (&L.n_claimed, 1u); atomicAdd (&L.cnt[2 * slot + strand], 1u); }
+                    adv = true;
+                  }                                     // else somebody else took the slot: look at the pair again
+                }
+              }
+              else if (++probes >= AG1_S / 2) { left = true; adv = true; }   // every slot holds another key
+              else pair = (pair + 1u) & (AG1_S / 2 - 1);
+            }
           }
-          else old = L.key[slot];
-          if (old == key) { atomicAdd ((w & 2ull) ? &L.cr[slot] : &L.cf[slot], 1u); done = true; }
-          else if (old == 0ull) break;                  // closed table, key absent
-          else slot = (slot + 1u) & (AG1_S - 1);
-        }
-        if (!done) {                                    // back to the front of the bucket (chunk id cached per lane)
-          const u32 o = atomicAdd (&L.n_ovf, 1u);
-          const u32 j = chunk_of_pos (BK, o);
-          if (j != oj) { oj = j; oc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
-          if (oc != TJ_NOCHUNK) BK.pool[(((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift))] = w;
+          if (left) {                                   // back to the front of the bucket (chunk id cached per lane)
+            const u32 o = atomicAdd (&L.n_ovf, 1u);
+            const u32 j = chunk_of_pos (BK, o);
+            if (j != oj) { oj = j; oc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
+            if (oc != TJ_NOCHUNK) BK.pool[(((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift))] = cur;
+          }
+          if (adv) {
+            r++; probes = 0;
+            cur = (r == 1u) ? w[1] : (r == 2u) ? w[2] : w[3];
+            pair = home (cur >> 2);
+          }
         }
       }
-      lds_barrier ();
+      ASTAMP (5);
     }
     __syncthreads ();
+    ASTAMP (6);
 
     u32 mine = 0;
     u64 metas[AG1_S / AG_BLOCK];
@@ -1141,8 +1207,8 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
     for (int r = 0; r < AG1_S / AG_BLOCK; r++) {
       const int slot = tid + r * AG_BLOCK;
       metas[r] = 0;
-      if (L.key[slot]) {
-        const u32 cf = L.cf[slot], cr = L.cr[slot];
+      if (L.key[slot] && L.key[slot] != AG1_MARK) {
+        const u32 cf = L.cnt[2 * slot], cr = L.cnt[2 * slot + 1];
         const u64 flag = (cf ? 1ull : 0ull) | (cr ? 2ull : 0ull);
         const u64 cnt = ((u64) cf + (u64) cr) & 0xFFFFFull;
         const int scnt = (cnt & 0x80000ull) ? (int) cnt - 0x100000 : (int) cnt;
@@ -1176,7 +1242,9 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
     __syncthreads ();
     n = L.n_ovf;
     __syncthreads ();
+    ASTAMP (7);
   }
+  ASTAMP_FLUSH;
 }
 
 // ---- W = 2 (k <= 28): word 0 of the record is never 0 and leaves bit 63 free, so it doubles as the slot's claim word:
