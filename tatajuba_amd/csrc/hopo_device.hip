@@ -1016,8 +1016,9 @@ __global__ void table_relayout_kernel (const u32 *__restrict__ old, u32 old_maxj
 #define AG_S        4096                // table slots
 #define AG_CLOSE_AT 1280                // stop admitting new keys beyond this many (one more batch may add 1024): load stays < 60 %
 #define AG_BLOCK    1024
+#define AG_NCH      512                 // chunk ids of a bucket cached in LDS (longer buckets look the rest up in the table)
 
-struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow; };
+struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow, sort_fallback, pad; };
 
 struct AggLds
 {
@@ -1073,6 +1074,7 @@ struct Agg1Lds
 {
   u64 key[AG1_S];                       // record >> 2 (never 0: the stored length of a tract is >= 2)
   u32 cnt[2 * AG1_S];                   // per slot: records seen on the forward / on the reverse strand
+  u32 chunk[AG_NCH];                    // the bucket's chunk ids
   u32 n_claimed, n_ovf, total;
   u32 wsum[AG_BLOCK / 64];
 };
@@ -1085,6 +1087,8 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
   const u32 bkt = blockIdx.x;
   u32 n = BK.cursors[bkt];
   const u64 km = kmask (k);
+  if (n) for (u32 j = (u32) tid; j <= chunk_of_pos (BK, n - 1u) && j < AG_NCH; j += AG_BLOCK) L.chunk[j] = bucket_chunk_id (BK, bkt, j, false, nullptr);
+  auto chunk_id = [&] (u32 j) { return j < AG_NCH ? L.chunk[j] : bucket_chunk_id (BK, bkt, j, false, nullptr); };
 
   ASTAMP_DECL;
   while (n > 0) {
@@ -1097,21 +1101,26 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
     // kernel sat at latency x (8 KB per CU in flight) = 1.4 TB/s whatever the table did.
     u64 wn[AG1_R];
     u32 vn = 0;
-    u32 cj = TJ_EMPTY, cc = TJ_NOCHUNK, oj = TJ_EMPTY, oc = TJ_NOCHUNK;
-    auto fetch = [&] (u32 first) {
+    // A round is AG_BLOCK * AG1_R consecutive records of the bucket: less than a chunk, so it lies in at most two
+    // chunks and everything about them is workgroup-uniform (chunk ids come from LDS: no global look-up whose wait
+    // would also wait for the records in flight).
+    auto fetch = [&] (u32 b0) {
       vn = 0;
 #pragma unroll
+      for (int r = 0; r < AG1_R; r++) wn[r] = 0;
+      if (b0 >= n) return;
+      const u32 ch = (u32) TJ_CH0 << BK.ch_shift;
+      const u32 j0 = chunk_of_pos (BK, b0), bound = (j0 + 1u) * ch;
+      const u32 c0 = chunk_id (j0), c1 = (bound < n) ? chunk_id (j0 + 1u) : TJ_NOCHUNK;
+      const u64 off0 = (u64) c0 * ch - (u64) j0 * ch, off1 = (u64) c1 * ch - (u64) bound;   // record index -> pool index
+#pragma unroll
       for (int r = 0; r < AG1_R; r++) {
-        const u32 idx = first + (u32) r * AG_BLOCK;
-        wn[r] = 0;
-        if (idx < n) {
-          const u32 j = chunk_of_pos (BK, idx);
-          if (j != cj) { cj = j; cc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
-          if (cc != TJ_NOCHUNK) { vn |= 1u << r; wn[r] = BK.pool[(((u64) cc * TJ_CH0) << BK.ch_shift) + (idx - ((j * TJ_CH0) << BK.ch_shift))]; }
-        }
+        const u32 idx = b0 + (u32) r * AG_BLOCK + (u32) tid;
+        const bool hi = idx >= bound;
+        if (idx < n && (hi ? c1 : c0) != TJ_NOCHUNK) { vn |= 1u << r; wn[r] = BK.pool[(hi ? off1 : off0) + idx]; }
       }
     };
-    fetch ((u32) tid);
+    fetch (0u);
     ASTAMP (1);
     for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK * AG1_R) {
       // this round's records have arrived (fetched one round ago).  The registers pass through the asm so that the
@@ -1124,7 +1133,7 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
 #pragma unroll
       for (int r = 0; r < AG1_R; r++) w[r] = wn[r];
       const u32 valid = vn;
-      fetch (b0 + AG_BLOCK * AG1_R + tid);
+      fetch (b0 + AG_BLOCK * AG1_R);
       ASTAMP (3);
       // One barrier per round: every lane holds its records of this round in registers, so the leftovers written below
       // (in place, from the front of the bucket: fewer than the records consumed so far) never land on a record
@@ -1185,8 +1194,7 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
           }
           if (left) {                                   // back to the front of the bucket (chunk id cached per lane)
             const u32 o = atomicAdd (&L.n_ovf, 1u);
-            const u32 j = chunk_of_pos (BK, o);
-            if (j != oj) { oj = j; oc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
+            const u32 j = chunk_of_pos (BK, o), oc = chunk_id (j);
             if (oc != TJ_NOCHUNK) BK.pool[(((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift))] = cur;
           }
           if (adv) {
@@ -1596,6 +1604,106 @@ void radix_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, lo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Ordering the kept set (the usual case: 1e5..1e6 records, where seven stable radix passes are all launch overhead):
+// one partition by the leading bits of the key into ~n/24 bins, then every bin is rank-sorted in LDS by one wavefront.
+// Keys compare as the reference's qsort does (src/hopo_counter.c:28-38): base, ctx0, ctx1, signed length, descending.
+
+#define BS_MAXBITS   16
+#define BS_RANK_MAX  512                // records of one bin a wavefront sorts in LDS; a fuller bin -> radix sort instead
+
+__device__ __forceinline__ u32 bin_of_record (u64 c0, u64 c1, u64 meta, int k, int nbits)
+{ // leading nbits (<= 1 + 4k) of [base:1][ctx0:2k][ctx1:2k], complemented: ascending bins = descending keys
+  const int kb = nbits - 1;
+  const u64 v = (2 * k >= kb) ? (c0 >> (2 * k - kb)) : ((c0 << (kb - 2 * k)) | (c1 >> (4 * k - kb)));
+  const u32 x = ((u32) (meta & 1ull) << kb) | (u32) v;
+  return ((1u << nbits) - 1u) - x;
+}
+
+// does record a come before record b?  (equal keys -- only the merge ever has them -- keep their input order)
+__device__ __forceinline__ bool record_before (u64 a0, u64 a1, u64 am, u32 ai, u64 b0, u64 b1, u64 bm, u32 bi)
+{
+  const u32 ab = (u32) am & 1u, bb = (u32) bm & 1u;
+  if (ab != bb) return ab > bb;
+  if (a0 != b0) return a0 > b0;
+  if (a1 != b1) return a1 > b1;
+  const u32 al = ((u32) (am >> TJ_META_LEN_SHIFT) & 0x3FFu) ^ 0x200u, bl = ((u32) (bm >> TJ_META_LEN_SHIFT) & 0x3FFu) ^ 0x200u;
+  if (al != bl) return al > bl;
+  return ai < bi;
+}
+
+__global__ __launch_bounds__ (256)
+void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32 *__restrict__ bins)
+{
+  for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < n; i += (long) gridDim.x * 256) {
+    const u64 *p = in + 3 * i;
+    atomicAdd (&bins[bin_of_record (p[0], p[1], p[2], k, nbits)], 1u);
+  }
+}
+
+// one workgroup: exclusive prefix of the bin counts -> binstart[0..nbins] and the scatter cursors (bins[] itself);
+// a bin above rank_max switches the whole sort to the radix path (flag in FinCounts)
+__global__ __launch_bounds__ (1024)
+void bin_scan_kernel (u32 *__restrict__ bins, int nbins, u32 *__restrict__ binstart, u32 rank_max, FinCounts *fin)
+{
+  __shared__ u32 wsum[16];
+  __shared__ u32 too_big;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (nbins + 1023) / 1024;
+  if (tid == 0) too_big = 0;
+  u32 sum = 0, mx = 0;
+  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < nbins) { const u32 v = bins[b]; sum += v; mx = max (mx, v); } }
+  const u32 incl = wave_inclusive_scan (sum);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads ();
+  if (mx > rank_max) too_big = 1u;
+  u32 run = incl - sum;
+  for (int w = 0; w < wave; w++) run += wsum[w];
+  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < nbins) { const u32 v = bins[b]; binstart[b] = run; bins[b] = run; run += v; } }
+  if (tid == 1023) binstart[nbins] = run;
+  __syncthreads ();
+  if (tid == 0 && too_big) fin->sort_fallback = 1u;
+}
+
+__global__ __launch_bounds__ (256)
+void bin_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, long n, int k, int nbits, u32 *__restrict__ cursors)
+{
+  for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < n; i += (long) gridDim.x * 256) {
+    const u64 *p = in + 3 * i;
+    const u64 a = p[0], b = p[1], m = p[2];
+    u64 *q = out + 3 * (u64) atomicAdd (&cursors[bin_of_record (a, b, m, k, nbits)], 1u);
+    q[0] = a; q[1] = b; q[2] = m;
+  }
+}
+
+// one wavefront per bin: the bin's records go to LDS, every lane counts the records that come before its own, and
+// that rank is the record's place in the output
+__global__ __launch_bounds__ (256)
+void bin_sort_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, const u32 *__restrict__ binstart, int nbins, const FinCounts *fin)
+{
+  __shared__ u64 rec[4][3 * BS_RANK_MAX];
+  if (fin->sort_fallback) return;                       // some bin is too full: the caller sorts with the radix passes
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u64 *R = rec[wave];
+  for (int bin = blockIdx.x * 4 + wave; bin < nbins; bin += gridDim.x * 4) {
+    const u32 st = binstart[bin], s = binstart[bin + 1] - st;
+    if (s == 0) continue;
+    if (s == 1) { if (lane < 3) out[3 * (u64) st + lane] = in[3 * (u64) st + lane]; continue; }
+    for (u32 w = lane; w < 3 * s; w += 64) R[w] = in[3 * (u64) st + w];
+    asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // wave-private LDS: in-order, only the data must have landed
+    __builtin_amdgcn_wave_barrier ();
+    for (u32 t = lane; t < s; t += 64) {
+      const u64 a0 = R[3 * t], a1 = R[3 * t + 1], am = R[3 * t + 2];
+      u32 rank = 0;
+      for (u32 j = 0; j < s; j++) rank += record_before (R[3 * j], R[3 * j + 1], R[3 * j + 2], j, a0, a1, am, t) ? 1u : 0u;
+      u64 *q = out + 3 * ((u64) st + rank);
+      q[0] = a0; q[1] = a1; q[2] = am;
+    }
+    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier ();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // exclusive scan of u32 arrays (three-kernel, recursive on block sums)
 
 #define SC_ITEMS 4096
@@ -1797,7 +1905,8 @@ struct tjamd_counter
   long n_raw_known = 0;       // exact after the last synchronisation
   long n_undefined = 0;
   double slack = 1.0;
-  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov_keys, cov_sums;
+  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov_keys, cov_sums, bins, binstart;
+  u32 bin_rank_max = BS_RANK_MAX;
   FinCounts *d_fin = nullptr, *h_fin = nullptr;
   long n_kept = 0; int n_idx = 0, coverage = 0, status = -1;
   hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_f0 = nullptr, ev_f1 = nullptr;
@@ -1837,6 +1946,8 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   hipDeviceProp_t prop;
   HIPCHK_NULL (hipGetDeviceProperties (&prop, device));
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const char *bm = getenv ("TATAJUBA_AMD_BIN_MAX");      // test hook: a smaller limit forces the radix path
+  if (bm && atoi (bm) >= 1 && atoi (bm) <= BS_RANK_MAX) c->bin_rank_max = (u32) atoi (bm);
   const char *sl = getenv ("TATAJUBA_AMD_BUCKET_SLACK");
   if (sl && atof (sl) >= 1.0) c->slack = atof (sl);
   HIPCHK_NULL (hipStreamCreateWithFlags (&c->own_stream, hipStreamNonBlocking));
@@ -2230,6 +2341,27 @@ static int radix_sort_records (tjamd_counter *c, u64 *&a, u64 *&b, long n)
 
 static unsigned grid_for (long n) { return (unsigned) std::max<long> (1, std::min<long> ((n + 255) / 256, 4096)); }
 
+// kept (n records) -> sorted in kept, through alt.  If a bin turns out too full the kernels leave kept untouched and
+// raise FinCounts::sort_fallback (seen by the caller at its next synchronisation).
+static int bin_sort_records (tjamd_counter *c, long n)
+{
+  int nbits = 6;
+  while (nbits < BS_MAXBITS && nbits < 1 + 4 * c->k && (24l << nbits) < n) nbits++;
+  nbits = std::min (nbits, 1 + 4 * c->k);
+  const int nbins = 1 << nbits;
+  int rc = ensure (c->bins, (size_t) (nbins + 1) * 4, c->stream);
+  if (!rc) rc = ensure (c->binstart, (size_t) (nbins + 1) * 4, c->stream);
+  if (rc) return rc;
+  HIPCHK (hipMemsetAsync (c->bins.p, 0, (size_t) nbins * 4, c->stream));
+  hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n, c->k, nbits, (u32 *) c->bins.p);
+  hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, (u32 *) c->bins.p, nbins, (u32 *) c->binstart.p, c->bin_rank_max, c->d_fin);
+  hipLaunchKernelGGL (bin_scatter_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n, c->k, nbits, (u32 *) c->bins.p);
+  hipLaunchKernelGGL (bin_sort_kernel, dim3 ((unsigned) std::min (nbins / 4 + 1, 4096)), dim3 (256), 0, c->stream, (const u64 *) c->alt.p, (u64 *) c->kept.p,
+                      (const u32 *) c->binstart.p, nbins, (const FinCounts *) c->d_fin);
+  HIPCHK (hipGetLastError ());
+  return TJAMD_OK;
+}
+
 extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_coverage, int *status)
 {
   if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
@@ -2274,27 +2406,35 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   if (!rc) rc = ensure (c->outpos, (size_t) n1 * 4, c->stream);
   if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n1) * 4, c->stream);
   if (rc) return rc;
-  u64 *a = (u64 *) c->kept.p, *b = (u64 *) c->alt.p;
-  rc = radix_sort_records (c, a, b, n1);
-  if (rc) return rc;
-  if (a != (u64 *) c->kept.p) std::swap (c->kept, c->alt);
-  c->n_kept = n1;
-
-  // step 4: contexts deep enough get an index range (reference :388-404)
-  const u64 *kept = (const u64 *) c->kept.p;
   u32 *flags = (u32 *) c->flags.p, *segid = (u32 *) c->segid.p, *headpos = (u32 *) c->headpos.p;
   u32 *keep = (u32 *) c->keep.p, *outpos = (u32 *) c->outpos.p;
-  hipLaunchKernelGGL (seg_heads_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, kept, n1, flags, 1);
-  HIPCHK (hipGetLastError ());
-  rc = exclusive_scan (c, flags, segid, n1, &c->d_fin->n_ctx, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
-  if (rc) return rc;
-  hipLaunchKernelGGL (seg_headpos_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u32 *) flags, (const u32 *) segid, n1, headpos);
-  HIPCHK (hipGetLastError ());
-  hipLaunchKernelGGL (ctx_decide_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, kept, n1, (const u32 *) headpos,
-                      (const u32 *) &c->d_fin->n_ctx, min_coverage, keep);
-  HIPCHK (hipGetLastError ());
-  HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK (hipStreamSynchronize (c->stream));
+  const u64 *kept = nullptr;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (attempt == 0) rc = bin_sort_records (c, n1);
+    else {                                              // a bin was too full for the LDS rank sort: kept is untouched
+      u64 *a = (u64 *) c->kept.p, *b = (u64 *) c->alt.p;
+      rc = radix_sort_records (c, a, b, n1);
+      if (!rc && a != (u64 *) c->kept.p) std::swap (c->kept, c->alt);
+    }
+    if (rc) return rc;
+    c->n_kept = n1;
+
+    // step 4: contexts deep enough get an index range (reference :388-404)
+    kept = (const u64 *) c->kept.p;
+    hipLaunchKernelGGL (seg_heads_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, kept, n1, flags, 1);
+    HIPCHK (hipGetLastError ());
+    rc = exclusive_scan (c, flags, segid, n1, &c->d_fin->n_ctx, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL (seg_headpos_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u32 *) flags, (const u32 *) segid, n1, headpos);
+    HIPCHK (hipGetLastError ());
+    hipLaunchKernelGGL (ctx_decide_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, kept, n1, (const u32 *) headpos,
+                        (const u32 *) &c->d_fin->n_ctx, min_coverage, keep);
+    HIPCHK (hipGetLastError ());
+    HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK (hipStreamSynchronize (c->stream));
+    if (attempt == 0 && c->h_fin->sort_fallback) continue;
+    break;
+  }
   const long n_ctx = c->h_fin->n_ctx;
   rc = exclusive_scan (c, keep, outpos, n_ctx, &c->d_fin->n_idx, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
   if (!rc) rc = ensure (c->idx_i, (size_t) n_ctx * 4, c->stream);

@@ -262,6 +262,32 @@ def test_finalise_synthetic(k, m, rb, mc):
     assert st == 0 and n > 0
 
 
+@pytest.mark.parametrize("k,m,limit", [(10, 3, 1), (25, 4, 2), (32, 3, 1), (2, 1, 1)])
+def test_finalise_radix_fallback(monkeypatch, k, m, limit):
+    # the kept set is ordered by a bin partition + rank sort; a bin fuller than the limit must switch the whole sort to
+    # the stable radix passes (the environment hook makes every bin "too full")
+    monkeypatch.setenv("TATAJUBA_AMD_BIN_MAX", str(limit))
+    st, n = check_finalise([tj.synth_stream(20000, 150, 100000)], k, m, 1, 3)
+    assert st == 0 and n > 0
+
+
+def test_finalise_skewed_bins():
+    # contexts that share their leading bases land in few bins: poly-A flanks with variation far from the tract
+    rng = random.Random(3)
+    reads = []
+    for i in range(3000):
+        far = "".join(rng.choice("ACGT") for _ in range(6))
+        tract = "C" * rng.choice([3, 4, 5, 6])
+        r = far + "A" * 14 + tract + "A" * 14 + far[::-1]
+        reads.append(r)
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        reads.append("".join(comp[ch] for ch in reversed(r)))
+    s = np.frombuffer(("\n".join(reads) + "\n").encode(), np.uint8)
+    for k in (16, 20):
+        st, n = check_finalise([s], k, 3, 1, 0)
+        assert st == 0 and n > (1000 if k == 20 else 10)
+
+
 def test_finalise_statuses_and_count_semantics():
     assert check_finalise([np.frombuffer(b"ACGT\n", np.uint8)], 3, 3, 1, 5)[0] == 1
     assert check_finalise([np.frombuffer(b"CCGAAAAGAT\n", np.uint8)], 3, 3, 1, 0)[0] == 2
