@@ -1675,34 +1675,6 @@ void bin_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, long
   }
 }
 
-// one wavefront per bin: the bin's records go to LDS, every lane counts the records that come before its own, and
-// that rank is the record's place in the output
-__global__ __launch_bounds__ (256)
-void bin_sort_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, const u32 *__restrict__ binstart, int nbins, const FinCounts *fin)
-{
-  __shared__ u64 rec[4][3 * BS_RANK_MAX];
-  if (fin->sort_fallback) return;                       // some bin is too full: the caller sorts with the radix passes
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  u64 *R = rec[wave];
-  for (int bin = blockIdx.x * 4 + wave; bin < nbins; bin += gridDim.x * 4) {
-    const u32 st = binstart[bin], s = binstart[bin + 1] - st;
-    if (s == 0) continue;
-    if (s == 1) { if (lane < 3) out[3 * (u64) st + lane] = in[3 * (u64) st + lane]; continue; }
-    for (u32 w = lane; w < 3 * s; w += 64) R[w] = in[3 * (u64) st + w];
-    asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // wave-private LDS: in-order, only the data must have landed
-    __builtin_amdgcn_wave_barrier ();
-    for (u32 t = lane; t < s; t += 64) {
-      const u64 a0 = R[3 * t], a1 = R[3 * t + 1], am = R[3 * t + 2];
-      u32 rank = 0;
-      for (u32 j = 0; j < s; j++) rank += record_before (R[3 * j], R[3 * j + 1], R[3 * j + 2], j, a0, a1, am, t) ? 1u : 0u;
-      u64 *q = out + 3 * ((u64) st + rank);
-      q[0] = a0; q[1] = a1; q[2] = am;
-    }
-    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier ();
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // exclusive scan of u32 arrays (three-kernel, recursive on block sums)
 
@@ -1807,20 +1779,39 @@ __global__ void ctx_write_kernel (long n1, const u32 *__restrict__ ctxpos, const
     }
 }
 
-// coverage: pooled 31-bit-truncated flanks weighted by count, largest pooled weight wins
+// coverage: pooled 31-bit-truncated flanks weighted by count, largest pooled weight wins (reference
+// src/hopo_counter.c:419-438).  Open-addressing table in HBM; a slot holds key + 1, 0 = empty.
+__device__ __forceinline__ void cov_add (u32 key31, int w, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
+{
+  const u32 tmask = (1u << log2t) - 1u, stored = key31 + 1u;
+  u32 slot = (key31 * 2654435761u) >> (32 - log2t);
+  for (u32 probe = 0; probe <= tmask; probe++) {
+    const u32 old = atomicCAS (&keys[slot], 0u, stored);
+    if (old == 0u || old == stored) { atomicAdd (&sums[slot], w); break; }
+    slot = (slot + 1u) & tmask;
+  }
+}
+
 __global__ void cov_insert_kernel (const u64 *__restrict__ kept, long n1, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
 {
-  const u32 tmask = (1u << log2t) - 1u;
   for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < 2 * n1; i += (long) gridDim.x * blockDim.x) {
     const long r = (i < n1) ? i : i - n1;
-    const u32 key = (u32) (kept[3 * r + (i < n1 ? 0 : 1)] & 0x7FFFFFFFull);
-    const int w = meta_count (kept[3 * r + 2]);
-    u32 slot = (key * 2654435761u) >> (32 - log2t);
-    for (u32 probe = 0; probe <= tmask; probe++) {
-      u32 old = atomicCAS (&keys[slot], 0xFFFFFFFFu, key);
-      if (old == 0xFFFFFFFFu || old == key) { atomicAdd (&sums[slot], w); break; }
-      slot = (slot + 1u) & tmask;
-    }
+    cov_add ((u32) (kept[3 * r + (i < n1 ? 0 : 1)] & 0x7FFFFFFFull), meta_count (kept[3 * r + 2]), keys, sums, log2t);
+  }
+}
+
+// largest pooled weight of the table slice this workgroup looks at -> atomicMax (one atomic per workgroup)
+__device__ __forceinline__ void cov_max_part (const u32 *__restrict__ keys, const int *__restrict__ sums, long t, int *result, int *s_best)
+{
+  int best = INT_MIN;
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < t; i += (long) gridDim.x * blockDim.x)
+    if (keys[i] != 0u) best = max (best, sums[i]);
+  for (int o = 32; o > 0; o >>= 1) best = max (best, __shfl_down (best, o));
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int) blockDim.x / 64; w++) best = max (best, s_best[w]);
+    if (best != INT_MIN) atomicMax (result, best);
   }
 }
 
@@ -1828,16 +1819,109 @@ __global__ __launch_bounds__ (256)
 void cov_max_kernel (const u32 *__restrict__ keys, const int *__restrict__ sums, long t, int *result)
 {
   __shared__ int s_best[4];
-  int best = INT_MIN;
-  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < t; i += (long) gridDim.x * blockDim.x)
-    if (keys[i] != 0xFFFFFFFFu) best = max (best, sums[i]);
-  for (int o = 32; o > 0; o >>= 1) best = max (best, __shfl_down (best, o));
-  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
-  __syncthreads ();
-  if (threadIdx.x == 0) {
-    best = max (max (s_best[0], s_best[1]), max (s_best[2], s_best[3]));
-    if (best != INT_MIN) atomicMax (result, best);      // one atomic per workgroup
+  cov_max_part (keys, sums, t, result, s_best);
+}
+
+// One wavefront per bin: the bin's records go to LDS, every lane counts the records that come before its own, and that
+// rank is the record's place in the output -- plus everything else the finalise step needs from the sorted order: a
+// context (base, ctx0, ctx1) never straddles bins (the bin is a prefix of it), so its depth, its first record and its
+// size are all found among the bin's records -- and the coverage table takes the records in any order.
+//   binctx[bin]        contexts of the bin that reach min_coverage
+//   tstart/tend[st+o]  index range of the o-th such context of the bin (st = first record of the bin)
+#define BSI_WAVES 2
+
+__global__ __launch_bounds__ (64 * BSI_WAVES)
+void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, const u32 *__restrict__ binstart, int nbins, const FinCounts *fin,
+                            int min_coverage, u32 *__restrict__ cov_keys, int *__restrict__ cov_sums, int log2t,
+                            u32 *__restrict__ binctx, u32 *__restrict__ tstart, u32 *__restrict__ tend)
+{
+  __shared__ u64 rec[BSI_WAVES][3 * BS_RANK_MAX];
+  __shared__ u32 hd[BSI_WAVES][BS_RANK_MAX], sz[BSI_WAVES][BS_RANK_MAX];
+  if (fin->sort_fallback) return;                       // some bin is too full: the caller takes the radix path
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u64 *R = rec[wave];
+  u32 *H = hd[wave], *E = sz[wave];
+  for (int bin = blockIdx.x * BSI_WAVES + wave; bin < nbins; bin += gridDim.x * BSI_WAVES) {
+    const u32 st = binstart[bin], s = binstart[bin + 1] - st;
+    if (s == 0) { if (lane == 0) binctx[bin] = 0; continue; }
+    for (u32 w = lane; w < 3 * s; w += 64) R[w] = in[3 * (u64) st + w];
+    asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // wave-private LDS: in-order, only the data must have landed
+    __builtin_amdgcn_wave_barrier ();
+    u32 nkeep = 0;
+    for (u32 t0 = 0; t0 < s; t0 += 64) {
+      const u32 t = t0 + lane;
+      bool keep = false;
+      if (t < s) {
+        const u64 a0 = R[3 * t], a1 = R[3 * t + 1], am = R[3 * t + 2];
+        const int w = meta_count (am);
+        cov_add ((u32) (a0 & 0x7FFFFFFFull), w, cov_keys, cov_sums, log2t);
+        cov_add ((u32) (a1 & 0x7FFFFFFFull), w, cov_keys, cov_sums, log2t);
+        u32 rank = 0, ctx_before = 0, ctx_size = 0;
+        int depth = 0;
+        for (u32 j = 0; j < s; j++) {
+          const u64 b0 = R[3 * j], b1 = R[3 * j + 1], bm = R[3 * j + 2];
+          const bool before = record_before (b0, b1, bm, j, a0, a1, am, t);
+          rank += before ? 1u : 0u;
+          if (b0 == a0 && b1 == a1 && ((bm ^ am) & 3ull) == 0ull) { ctx_size++; depth += meta_count (bm); ctx_before += before ? 1u : 0u; }
+        }
+        u64 *q = out + 3 * ((u64) st + rank);
+        q[0] = a0; q[1] = a1; q[2] = am;
+        keep = (ctx_before == 0u) && depth >= min_coverage;      // first record of its context, context deep enough
+        H[t] = rank | (keep ? 0x80000000u : 0u);
+        E[t] = ctx_size;
+      }
+      nkeep += (u32) __popcll (__ballot (keep));
+    }
+    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier ();
+    for (u32 t = lane; t < s; t += 64) {
+      const u32 h = H[t];
+      if (h & 0x80000000u) {
+        const u32 rank = h & 0x7FFFFFFFu;
+        u32 o = 0;
+        for (u32 j = 0; j < s; j++) { const u32 g = H[j]; o += ((g & 0x80000000u) && (g & 0x7FFFFFFFu) < rank) ? 1u : 0u; }
+        tstart[st + o] = st + rank;
+        tend[st + o] = st + rank + E[t];
+      }
+    }
+    if (lane == 0) binctx[bin] = nkeep;
+    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier ();
   }
+}
+
+// one workgroup: exclusive prefix of binctx -> binout, number of index ranges, coverage start value
+__global__ __launch_bounds__ (1024)
+void bin_ctx_scan_kernel (const u32 *__restrict__ binctx, int nbins, u32 *__restrict__ binout, FinCounts *fin)
+{
+  __shared__ u32 wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (nbins + 1023) / 1024;
+  u32 sum = 0;
+  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < nbins) sum += binctx[b]; }
+  const u32 incl = wave_inclusive_scan (sum);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads ();
+  u32 run = incl - sum;
+  for (int w = 0; w < wave; w++) run += wsum[w];
+  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < nbins) { binout[b] = run; run += binctx[b]; } }
+  if (tid == 1023 && !fin->sort_fallback) { fin->n_idx = run; fin->coverage = INT_MIN; }
+}
+
+// index ranges in order (reference: idx_initial / idx_final, src/hopo_counter.c:388-404) + the coverage maximum
+__global__ __launch_bounds__ (256)
+void bin_ctx_write_kernel (const u32 *__restrict__ binstart, const u32 *__restrict__ binctx, const u32 *__restrict__ binout, int nbins,
+                           const u32 *__restrict__ tstart, const u32 *__restrict__ tend, int *__restrict__ idx_initial, int *__restrict__ idx_final,
+                           const u32 *__restrict__ cov_keys, const int *__restrict__ cov_sums, long t, FinCounts *fin)
+{
+  __shared__ int s_best[4];
+  if (fin->sort_fallback) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int bin = blockIdx.x * 4 + wave; bin < nbins; bin += gridDim.x * 4) {
+    const u32 cnt = binctx[bin], st = binstart[bin], o0 = binout[bin];
+    for (u32 o = lane; o < cnt; o += 64) { idx_initial[o0 + o] = (int) tstart[st + o]; idx_final[o0 + o] = (int) tend[st + o]; }
+  }
+  cov_max_part (cov_keys, cov_sums, t, &fin->coverage, s_best);
 }
 
 __global__ void set_int_kernel (int *p, int v) { *p = v; }
@@ -1905,7 +1989,7 @@ struct tjamd_counter
   long n_raw_known = 0;       // exact after the last synchronisation
   long n_undefined = 0;
   double slack = 1.0;
-  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov_keys, cov_sums, bins, binstart;
+  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov, bins, binstart, binctx;
   u32 bin_rank_max = BS_RANK_MAX;
   FinCounts *d_fin = nullptr, *h_fin = nullptr;
   long n_kept = 0; int n_idx = 0, coverage = 0, status = -1;
@@ -1974,7 +2058,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   (void) hipSetDevice (c->device);
   (void) hipStreamSynchronize (c->stream);
   DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
-                   &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov_keys, &c->cov_sums};
+                   &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx};
   for (DevBuf *b : all) release (*b);
   if (c->d_ctr) (void) hipFree (c->d_ctr);
   if (c->d_lctr) (void) hipFree (c->d_lctr);
@@ -2341,24 +2425,111 @@ static int radix_sort_records (tjamd_counter *c, u64 *&a, u64 *&b, long n)
 
 static unsigned grid_for (long n) { return (unsigned) std::max<long> (1, std::min<long> ((n + 255) / 256, 4096)); }
 
-// kept (n records) -> sorted in kept, through alt.  If a bin turns out too full the kernels leave kept untouched and
-// raise FinCounts::sort_fallback (seen by the caller at its next synchronisation).
-static int bin_sort_records (tjamd_counter *c, long n)
+// ---- finalise steps 3-4 + coverage, two ways --------------------------------------------------------------------
+
+static int cov_table_bits (long n1) { int b = 10; while ((1l << b) < 8 * n1 && b < 31) b++; return b; }
+
+// radix path: stable LSD sort, then heads / scans / decisions as separate kernels (any bin occupancy, any size)
+static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
+{
+  int rc = ensure (c->alt, (size_t) n1 * 24, c->stream);
+  if (!rc) rc = ensure (c->flags, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->segid, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->headpos, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->keep, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->outpos, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n1) * 4, c->stream);
+  if (rc) return rc;
+  u64 *a = (u64 *) c->kept.p, *b = (u64 *) c->alt.p;
+  rc = radix_sort_records (c, a, b, n1);
+  if (rc) return rc;
+  if (a != (u64 *) c->kept.p) std::swap (c->kept, c->alt);
+
+  // step 4: contexts deep enough get an index range (reference :388-404)
+  const u64 *kept = (const u64 *) c->kept.p;
+  u32 *flags = (u32 *) c->flags.p, *segid = (u32 *) c->segid.p, *headpos = (u32 *) c->headpos.p;
+  u32 *keep = (u32 *) c->keep.p, *outpos = (u32 *) c->outpos.p;
+  hipLaunchKernelGGL (seg_heads_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, kept, n1, flags, 1);
+  HIPCHK (hipGetLastError ());
+  rc = exclusive_scan (c, flags, segid, n1, &c->d_fin->n_ctx, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
+  if (rc) return rc;
+  hipLaunchKernelGGL (seg_headpos_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u32 *) flags, (const u32 *) segid, n1, headpos);
+  HIPCHK (hipGetLastError ());
+  hipLaunchKernelGGL (ctx_decide_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, kept, n1, (const u32 *) headpos,
+                      (const u32 *) &c->d_fin->n_ctx, min_coverage, keep);
+  HIPCHK (hipGetLastError ());
+  HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK (hipStreamSynchronize (c->stream));
+  const long n_ctx = c->h_fin->n_ctx;
+  rc = exclusive_scan (c, keep, outpos, n_ctx, &c->d_fin->n_idx, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
+  if (!rc) rc = ensure (c->idx_i, (size_t) n_ctx * 4, c->stream);
+  if (!rc) rc = ensure (c->idx_f, (size_t) n_ctx * 4, c->stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL (ctx_write_kernel, dim3 (grid_for (n_ctx)), dim3 (256), 0, c->stream, n1, (const u32 *) headpos, (const u32 *) &c->d_fin->n_ctx,
+                      (const u32 *) keep, (const u32 *) outpos, (int *) c->idx_i.p, (int *) c->idx_f.p);
+  HIPCHK (hipGetLastError ());
+
+  // coverage (reference :419-438)
+  const int log2t = cov_table_bits (n1);
+  const long t = 1l << log2t;
+  rc = ensure (c->cov, (size_t) t * 8, c->stream);
+  if (rc) return rc;
+  u32 *ckeys = (u32 *) c->cov.p;
+  int *csums = (int *) c->cov.p + t;
+  HIPCHK (hipMemsetAsync (c->cov.p, 0, (size_t) t * 8, c->stream));
+  hipLaunchKernelGGL (set_int_kernel, dim3 (1), dim3 (1), 0, c->stream, &c->d_fin->coverage, INT_MIN);
+  hipLaunchKernelGGL (cov_insert_kernel, dim3 (grid_for (2 * n1)), dim3 (256), 0, c->stream, kept, n1, ckeys, csums, log2t);
+  HIPCHK (hipGetLastError ());
+  hipLaunchKernelGGL (cov_max_kernel, dim3 (std::min<unsigned> (grid_for (t), 256u)), dim3 (256), 0, c->stream, (const u32 *) ckeys, (const int *) csums, t, &c->d_fin->coverage);
+  HIPCHK (hipGetLastError ());
+  HIPCHK (hipEventRecord (c->ev_f1, c->stream));
+  c->fin_timed = true;
+  HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK (hipStreamSynchronize (c->stream));
+  return TJAMD_OK;
+}
+
+// binned path: kept (n1 records, any order) -> sorted kept, idx_i / idx_f, FinCounts{n_idx, coverage}; one host
+// synchronisation at the end.  If a bin turns out too full every kernel after the bin scan does nothing, kept stays as
+// it was and FinCounts::sort_fallback comes back set.
+static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
 {
   int nbits = 6;
-  while (nbits < BS_MAXBITS && nbits < 1 + 4 * c->k && (24l << nbits) < n) nbits++;
+  while (nbits < BS_MAXBITS && nbits < 1 + 4 * c->k && (24l << nbits) < n1) nbits++;
   nbits = std::min (nbits, 1 + 4 * c->k);
   const int nbins = 1 << nbits;
-  int rc = ensure (c->bins, (size_t) (nbins + 1) * 4, c->stream);
+  const int log2t = cov_table_bits (n1);
+  const long t = 1l << log2t;
+  int rc = ensure (c->alt, (size_t) n1 * 24, c->stream);
+  if (!rc) rc = ensure (c->bins, (size_t) (nbins + 1) * 4, c->stream);
   if (!rc) rc = ensure (c->binstart, (size_t) (nbins + 1) * 4, c->stream);
+  if (!rc) rc = ensure (c->binctx, (size_t) nbins * 8, c->stream);
+  if (!rc) rc = ensure (c->headpos, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->outpos, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->idx_i, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->idx_f, (size_t) n1 * 4, c->stream);
+  if (!rc) rc = ensure (c->cov, (size_t) t * 8, c->stream);
   if (rc) return rc;
-  HIPCHK (hipMemsetAsync (c->bins.p, 0, (size_t) nbins * 4, c->stream));
-  hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n, c->k, nbits, (u32 *) c->bins.p);
-  hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, (u32 *) c->bins.p, nbins, (u32 *) c->binstart.p, c->bin_rank_max, c->d_fin);
-  hipLaunchKernelGGL (bin_scatter_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n, c->k, nbits, (u32 *) c->bins.p);
-  hipLaunchKernelGGL (bin_sort_kernel, dim3 ((unsigned) std::min (nbins / 4 + 1, 4096)), dim3 (256), 0, c->stream, (const u64 *) c->alt.p, (u64 *) c->kept.p,
-                      (const u32 *) c->binstart.p, nbins, (const FinCounts *) c->d_fin);
+  u32 *bins = (u32 *) c->bins.p, *binstart = (u32 *) c->binstart.p, *binctx = (u32 *) c->binctx.p, *binout = binctx + nbins;
+  u32 *tstart = (u32 *) c->headpos.p, *tend = (u32 *) c->outpos.p;
+  u32 *ckeys = (u32 *) c->cov.p;
+  int *csums = (int *) c->cov.p + t;
+  HIPCHK (hipMemsetAsync (bins, 0, (size_t) nbins * 4, c->stream));
+  HIPCHK (hipMemsetAsync (c->cov.p, 0, (size_t) t * 8, c->stream));
+  hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n1, c->k, nbits, bins);
+  hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, bins, nbins, binstart, c->bin_rank_max, c->d_fin);
+  hipLaunchKernelGGL (bin_scatter_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins);
+  hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 8192)), dim3 (64 * BSI_WAVES), 0, c->stream,
+                      (const u64 *) c->alt.p, (u64 *) c->kept.p, (const u32 *) binstart, nbins, (const FinCounts *) c->d_fin, min_coverage,
+                      ckeys, csums, log2t, binctx, tstart, tend);
+  hipLaunchKernelGGL (bin_ctx_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, (const u32 *) binctx, nbins, binout, c->d_fin);
+  hipLaunchKernelGGL (bin_ctx_write_kernel, dim3 (256), dim3 (256), 0, c->stream, (const u32 *) binstart, (const u32 *) binctx, (const u32 *) binout, nbins,
+                      (const u32 *) tstart, (const u32 *) tend, (int *) c->idx_i.p, (int *) c->idx_f.p, (const u32 *) ckeys, (const int *) csums, t, c->d_fin);
   HIPCHK (hipGetLastError ());
+  HIPCHK (hipEventRecord (c->ev_f1, c->stream));
+  c->fin_timed = true;
+  HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK (hipStreamSynchronize (c->stream));
   return TJAMD_OK;
 }
 
@@ -2397,71 +2568,12 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
     c->status = 2; if (status) *status = 2; return TJAMD_OK;
   }
 
-  // step 3: order the survivors as the reference's qsort does (base, ctx0, ctx1, length, all descending)
-  rc = ensure (c->alt, (size_t) n1 * 24, c->stream);
-  if (!rc) rc = ensure (c->flags, (size_t) n1 * 4, c->stream);
-  if (!rc) rc = ensure (c->segid, (size_t) n1 * 4, c->stream);
-  if (!rc) rc = ensure (c->headpos, (size_t) n1 * 4, c->stream);
-  if (!rc) rc = ensure (c->keep, (size_t) n1 * 4, c->stream);
-  if (!rc) rc = ensure (c->outpos, (size_t) n1 * 4, c->stream);
-  if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n1) * 4, c->stream);
+  // steps 3-4 + coverage: bin partition, then one pass per bin sorts it and derives the context index ranges and the
+  // coverage table entries; the stable radix passes + separate index kernels take over if a bin is too full.
+  c->n_kept = n1;
+  rc = finalise_binned (c, n1, min_coverage);
+  if (!rc && c->h_fin->sort_fallback) rc = finalise_radix (c, n1, min_coverage);
   if (rc) return rc;
-  u32 *flags = (u32 *) c->flags.p, *segid = (u32 *) c->segid.p, *headpos = (u32 *) c->headpos.p;
-  u32 *keep = (u32 *) c->keep.p, *outpos = (u32 *) c->outpos.p;
-  const u64 *kept = nullptr;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    if (attempt == 0) rc = bin_sort_records (c, n1);
-    else {                                              // a bin was too full for the LDS rank sort: kept is untouched
-      u64 *a = (u64 *) c->kept.p, *b = (u64 *) c->alt.p;
-      rc = radix_sort_records (c, a, b, n1);
-      if (!rc && a != (u64 *) c->kept.p) std::swap (c->kept, c->alt);
-    }
-    if (rc) return rc;
-    c->n_kept = n1;
-
-    // step 4: contexts deep enough get an index range (reference :388-404)
-    kept = (const u64 *) c->kept.p;
-    hipLaunchKernelGGL (seg_heads_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, kept, n1, flags, 1);
-    HIPCHK (hipGetLastError ());
-    rc = exclusive_scan (c, flags, segid, n1, &c->d_fin->n_ctx, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
-    if (rc) return rc;
-    hipLaunchKernelGGL (seg_headpos_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u32 *) flags, (const u32 *) segid, n1, headpos);
-    HIPCHK (hipGetLastError ());
-    hipLaunchKernelGGL (ctx_decide_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, kept, n1, (const u32 *) headpos,
-                        (const u32 *) &c->d_fin->n_ctx, min_coverage, keep);
-    HIPCHK (hipGetLastError ());
-    HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK (hipStreamSynchronize (c->stream));
-    if (attempt == 0 && c->h_fin->sort_fallback) continue;
-    break;
-  }
-  const long n_ctx = c->h_fin->n_ctx;
-  rc = exclusive_scan (c, keep, outpos, n_ctx, &c->d_fin->n_idx, (u32 *) c->scan_tmp.p, c->scan_tmp.cap / 4);
-  if (!rc) rc = ensure (c->idx_i, (size_t) n_ctx * 4, c->stream);
-  if (!rc) rc = ensure (c->idx_f, (size_t) n_ctx * 4, c->stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL (ctx_write_kernel, dim3 (grid_for (n_ctx)), dim3 (256), 0, c->stream, n1, (const u32 *) headpos, (const u32 *) &c->d_fin->n_ctx,
-                      (const u32 *) keep, (const u32 *) outpos, (int *) c->idx_i.p, (int *) c->idx_f.p);
-  HIPCHK (hipGetLastError ());
-
-  // coverage (reference :419-438)
-  int log2t = 10;
-  while ((1l << log2t) < 8 * n1 && log2t < 31) log2t++;
-  const long t = 1l << log2t;
-  rc = ensure (c->cov_keys, (size_t) t * 4, c->stream);
-  if (!rc) rc = ensure (c->cov_sums, (size_t) t * 4, c->stream);
-  if (rc) return rc;
-  HIPCHK (hipMemsetAsync (c->cov_keys.p, 0xFF, (size_t) t * 4, c->stream));
-  HIPCHK (hipMemsetAsync (c->cov_sums.p, 0, (size_t) t * 4, c->stream));
-  hipLaunchKernelGGL (set_int_kernel, dim3 (1), dim3 (1), 0, c->stream, &c->d_fin->coverage, INT_MIN);
-  hipLaunchKernelGGL (cov_insert_kernel, dim3 (grid_for (2 * n1)), dim3 (256), 0, c->stream, kept, n1, (u32 *) c->cov_keys.p, (int *) c->cov_sums.p, log2t);
-  HIPCHK (hipGetLastError ());
-  hipLaunchKernelGGL (cov_max_kernel, dim3 (std::min<unsigned> (grid_for (t), 256u)), dim3 (256), 0, c->stream, (const u32 *) c->cov_keys.p, (const int *) c->cov_sums.p, t, &c->d_fin->coverage);
-  HIPCHK (hipGetLastError ());
-  HIPCHK (hipEventRecord (c->ev_f1, c->stream));
-  c->fin_timed = true;
-  HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK (hipStreamSynchronize (c->stream));
   c->n_idx = (int) c->h_fin->n_idx;
   if (c->n_idx == 0) { c->status = 3; if (status) *status = 3; return TJAMD_OK; }   // reference :406-411 (coverage not estimated)
   c->coverage = c->h_fin->coverage;
