@@ -87,13 +87,15 @@ struct TileLds
 struct DevCounters
 {
   u64 n_rec;        // records appended to the located list
-  u64 n_fix;        // pending non-ACGTU runs (see nrun_fixup kernels)
+  u64 n_fix_unused;
   u64 n_undefined;  // qualifying non-ACGTU runs without an earlier tract in the read (reference: uninitialised memory)
   u64 n_null;       // padding records written into the buckets (reserved slots that stayed empty)
   u32 overflow;     // output list / a bucket too small
   u32 fix_overflow; // fix list too small
-  u32 work;         // next unassigned tile (workgroups take groups of TJ_TILE_GROUP tiles)
-  u32 pad;
+  u32 pad[2];
+  // per-launch counters, double-buffered: launch i works on lc[i & 1] and zeroes lc[(i + 1) & 1] for the next launch
+  // (no memset between launches)
+  struct { u64 n_fix; u32 work, pad; } lc[2];
 };
 
 #define TJ_TILE_GROUP 16
@@ -364,7 +366,7 @@ __device__ __noinline__ EdgeChunk edge_chunk (const uint8_t *__restrict__ seq, l
 // "prefetch" was waited for at the first LDS instruction after its issue.
 template <int BLOCK, int TILE, int CANDDIV, class Sink>
 __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
-                                            TileLds<BLOCK, TILE, CANDDIV> &T, uint4 *raw, Sink &sink, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
+                                            TileLds<BLOCK, TILE, CANDDIV> &T, uint4 *raw, Sink &sink, DevCounters *ctr, FixEntry *fix, u32 fix_cap, int par)
 {
   typedef TileLds<BLOCK, TILE, CANDDIV> G;
   const int tid = threadIdx.x;
@@ -373,7 +375,10 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
 
   // Tiles are handed out dynamically in groups of TJ_TILE_GROUP (one global atomic per group): workgroups differ in
   // how many tracts their tiles hold, and a static split leaves the slow ones running alone at the end.
-  if (tid == 0) { T.odd[0] = 0; T.odd[1] = 0; T.grp[0] = atomicAdd (&ctr->work, (u32) TJ_TILE_GROUP); }
+  if (tid == 0) {
+    T.odd[0] = 0; T.odd[1] = 0; T.grp[0] = atomicAdd (&ctr->lc[par].work, (u32) TJ_TILE_GROUP);
+    if (blockIdx.x == 0) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; }
+  }
   lds_barrier ();
   long tile = (long) T.grp[0];
   long grp_end = tile + TJ_TILE_GROUP;
@@ -389,7 +394,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
   STAMP_DECL;
   while (tile < n_tiles) {
     STAMP (0);
-    if (tid == 0 && tile + TJ_TILE_GROUP == grp_end) T.grp[gpar ^ 1u] = atomicAdd (&ctr->work, (u32) TJ_TILE_GROUP);  // first tile of a group: reserve the next
+    if (tid == 0 && tile + TJ_TILE_GROUP == grp_end) T.grp[gpar ^ 1u] = atomicAdd (&ctr->lc[par].work, (u32) TJ_TILE_GROUP);  // first tile of a group: reserve the next
     const long g0 = tile * (long) TILE - TJ_HL;         // stream position of window byte 0 (may be negative)
 
     // ---- phase 1: classify the prefetched chunks into LDS, then prefetch the next tile ------------------------
@@ -568,7 +573,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
             have = true;
           }
           else {                                      // non-ACGTU run: context comes from the previous tract of the read
-            u64 at = atomicAdd (&ctr->n_fix, 1ull);
+            u64 at = atomicAdd ((unsigned long long *) &ctr->lc[par].n_fix, 1ull);
             if (at < fix_cap) { fix[at].pos = gs; fix[at].len = len; }
             else ctr->fix_overflow = 1u;
           }
@@ -632,18 +637,18 @@ struct ListSink
 
 __global__ __launch_bounds__ (256)
 void scan_list_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
-                       u64 *__restrict__ out, u64 cap, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
+                       u64 *__restrict__ out, u64 cap, DevCounters *ctr, FixEntry *fix, u32 fix_cap, int par)
 {
   __shared__ TileLds<256, 4096, 1> T;
   __shared__ uint4 raw[TileLds<256, 4096, 1>::NCHUNK];
   ListSink sink = {out, cap, ctr};
-  scan_tiles<256, 4096, 1> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap);
+  scan_tiles<256, 4096, 1> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap, par);
 }
 
 __global__ void nrun_fixup_list_kernel (const uint8_t *__restrict__ seq, long n_bytes, int k, int mprime,
-                                        u64 *__restrict__ out, u64 cap, DevCounters *ctr, const FixEntry *fix, u32 fix_cap)
+                                        u64 *__restrict__ out, u64 cap, DevCounters *ctr, const FixEntry *fix, u32 fix_cap, int par)
 {
-  u64 n_fix = ctr->n_fix;
+  u64 n_fix = ctr->lc[par].n_fix;
   if (n_fix > fix_cap) n_fix = fix_cap;
   for (u64 i = blockIdx.x * (u64) blockDim.x + threadIdx.x; i < n_fix; i += (u64) gridDim.x * blockDim.x) {
     u64 c0, c1; u32 base, flag;
@@ -937,22 +942,22 @@ struct StageSink
 template <int W>
 __global__ __launch_bounds__ (TJ_SB_BLOCK, 6)
 void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
-                       Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap)
+                       Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap, int par)
 {
   __shared__ TileLds<TJ_SB_BLOCK, TJ_SB_TILE> T;
   __shared__ uint4 raw[TileLds<TJ_SB_BLOCK, TJ_SB_TILE>::NCHUNK];
   __shared__ StageLds<W> SL;
   StageSink<W, TJ_SB_BLOCK> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
   sink.start ();
-  scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE, 2> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap);
+  scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE, 2> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap, par);
   sink.finish ();
 }
 
 template <int W>
 __global__ void nrun_fixup_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, int k, int mprime,
-                                        Buckets BK, DevCounters *ctr, const FixEntry *fix, u32 fix_cap)
+                                        Buckets BK, DevCounters *ctr, const FixEntry *fix, u32 fix_cap, int par)
 {
-  u64 n_fix = ctr->n_fix;
+  u64 n_fix = ctr->lc[par].n_fix;
   if (n_fix > fix_cap) n_fix = fix_cap;
   for (u64 i = blockIdx.x * (u64) blockDim.x + threadIdx.x; i < n_fix; i += (u64) gridDim.x * blockDim.x) {
     u64 c0, c1; u32 base, flag;
@@ -996,6 +1001,15 @@ __global__ void init_table_kernel (u32 *table, u32 maxj, u32 *pool_next)
   const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < TJ_P) table[(u64) b * maxj] = b;
   if (b == 0) *pool_next = TJ_P;
+}
+
+// empty buckets: cursors 0, every bucket owns chunk b as its chunk 0, the rest of the table unclaimed, pool_next = TJ_P
+__global__ void clear_buckets_kernel (u32 *cursors, u64 *n_null, u32 *table, u32 maxj)
+{
+  const u64 i0 = blockIdx.x * (u64) blockDim.x + threadIdx.x;
+  if (i0 < TJ_P) cursors[i0] = 0;
+  if (i0 == 0) { cursors[TJ_P] = TJ_P; *n_null = 0; }
+  if (table) for (u64 i = i0; i < (u64) TJ_P * maxj; i += (u64) gridDim.x * blockDim.x) table[i] = (i % maxj == 0) ? (u32) (i / maxj) : TJ_EMPTY;
 }
 
 // chunk table with a longer row
@@ -1605,11 +1619,11 @@ void radix_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, lo
 
 // ---------------------------------------------------------------------------------------------------------------
 // Ordering the kept set (the usual case: 1e5..1e6 records, where seven stable radix passes are all launch overhead):
-// one partition by the leading bits of the key into ~n/24 bins, then every bin is rank-sorted in LDS by one wavefront.
+// one partition by the leading bits of the key into ~n/32 bins, then every bin is rank-sorted in LDS by one wavefront.
 // Keys compare as the reference's qsort does (src/hopo_counter.c:28-38): base, ctx0, ctx1, signed length, descending.
 
-#define BS_MAXBITS   16
-#define BS_RANK_MAX  512                // records of one bin a wavefront sorts in LDS; a fuller bin -> radix sort instead
+#define BS_MAXBITS   14
+#define BS_RANK_MAX  256                // records of one bin a wavefront sorts in LDS; a fuller bin -> radix sort instead
 
 __device__ __forceinline__ u32 bin_of_record (u64 c0, u64 c1, u64 meta, int k, int nbits)
 { // leading nbits (<= 1 + 4k) of [base:1][ctx0:2k][ctx1:2k], complemented: ascending bins = descending keys
@@ -1640,28 +1654,44 @@ void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32
   }
 }
 
-// one workgroup: exclusive prefix of the bin counts -> binstart[0..nbins] and the scatter cursors (bins[] itself);
-// a bin above rank_max switches the whole sort to the radix path (flag in FinCounts)
+// Exclusive prefix of n <= BS_MAXBINS values by one workgroup of 1024 threads: coalesced load into LDS, every thread
+// sums a contiguous slice, one scan over the slice sums, coalesced store.  Returns the total; vmax = largest value.
+#define BS_MAXBINS (1 << BS_MAXBITS)
+
+struct WgScanLds { u32 a[BS_MAXBINS]; u32 wsum[16]; u32 vmax; };
+
+__device__ __forceinline__ u32 wg_exclusive_scan (const u32 *__restrict__ in, int n, u32 *__restrict__ out, u32 *__restrict__ out2, WgScanLds &L, u32 &vmax)
+{
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + 1023) / 1024;
+  if (tid == 0) L.vmax = 0;
+  for (int i = tid; i < n; i += 1024) L.a[i] = in[i];
+  __syncthreads ();
+  u32 sum = 0, mx = 0;
+  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < n) { const u32 v = L.a[b]; sum += v; mx = max (mx, v); } }
+  const u32 incl = wave_inclusive_scan (sum);
+  if (lane == 63) L.wsum[wave] = incl;
+  for (int o = 32; o > 0; o >>= 1) mx = max (mx, (u32) __shfl_down ((int) mx, o));
+  if (lane == 0 && mx) atomicMax (&L.vmax, mx);
+  __syncthreads ();
+  u32 run = incl - sum, total = 0;
+  for (int w = 0; w < 16; w++) { const u32 x = L.wsum[w]; if (w < wave) run += x; total += x; }
+  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < n) { const u32 v = L.a[b]; L.a[b] = run; run += v; } }
+  __syncthreads ();
+  for (int i = tid; i < n; i += 1024) { const u32 v = L.a[i]; out[i] = v; if (out2) out2[i] = v; }
+  vmax = L.vmax;
+  return total;
+}
+
+// bin counts -> binstart[0..nbins] and the scatter cursors (bins[] itself); a bin above rank_max switches the whole
+// sort to the radix path (flag in FinCounts)
 __global__ __launch_bounds__ (1024)
 void bin_scan_kernel (u32 *__restrict__ bins, int nbins, u32 *__restrict__ binstart, u32 rank_max, FinCounts *fin)
 {
-  __shared__ u32 wsum[16];
-  __shared__ u32 too_big;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (nbins + 1023) / 1024;
-  if (tid == 0) too_big = 0;
-  u32 sum = 0, mx = 0;
-  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < nbins) { const u32 v = bins[b]; sum += v; mx = max (mx, v); } }
-  const u32 incl = wave_inclusive_scan (sum);
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads ();
-  if (mx > rank_max) too_big = 1u;
-  u32 run = incl - sum;
-  for (int w = 0; w < wave; w++) run += wsum[w];
-  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < nbins) { const u32 v = bins[b]; binstart[b] = run; bins[b] = run; run += v; } }
-  if (tid == 1023) binstart[nbins] = run;
-  __syncthreads ();
-  if (tid == 0 && too_big) fin->sort_fallback = 1u;
+  __shared__ WgScanLds L;
+  u32 vmax;
+  const u32 total = wg_exclusive_scan (bins, nbins, binstart, bins, L, vmax);
+  if (threadIdx.x == 0) { binstart[nbins] = total; if (vmax > rank_max) fin->sort_fallback = 1u; }
 }
 
 __global__ __launch_bounds__ (256)
@@ -1828,7 +1858,7 @@ void cov_max_kernel (const u32 *__restrict__ keys, const int *__restrict__ sums,
 // size are all found among the bin's records -- and the coverage table takes the records in any order.
 //   binctx[bin]        contexts of the bin that reach min_coverage
 //   tstart/tend[st+o]  index range of the o-th such context of the bin (st = first record of the bin)
-#define BSI_WAVES 2
+#define BSI_WAVES 1
 
 __global__ __launch_bounds__ (64 * BSI_WAVES)
 void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, const u32 *__restrict__ binstart, int nbins, const FinCounts *fin,
@@ -1894,18 +1924,10 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
 __global__ __launch_bounds__ (1024)
 void bin_ctx_scan_kernel (const u32 *__restrict__ binctx, int nbins, u32 *__restrict__ binout, FinCounts *fin)
 {
-  __shared__ u32 wsum[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (nbins + 1023) / 1024;
-  u32 sum = 0;
-  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < nbins) sum += binctx[b]; }
-  const u32 incl = wave_inclusive_scan (sum);
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads ();
-  u32 run = incl - sum;
-  for (int w = 0; w < wave; w++) run += wsum[w];
-  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < nbins) { binout[b] = run; run += binctx[b]; } }
-  if (tid == 1023 && !fin->sort_fallback) { fin->n_idx = run; fin->coverage = INT_MIN; }
+  __shared__ WgScanLds L;
+  u32 vmax;
+  const u32 total = wg_exclusive_scan (binctx, nbins, binout, nullptr, L, vmax);
+  if (threadIdx.x == 0 && !fin->sort_fallback) { fin->n_idx = total; fin->coverage = INT_MIN; }
 }
 
 // index ranges in order (reference: idx_initial / idx_final, src/hopo_counter.c:388-404) + the coverage maximum
@@ -1996,6 +2018,8 @@ struct tjamd_counter
   hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_f0 = nullptr, ev_f1 = nullptr;
   bool scan_timed = false, fin_timed = false;
   long last_scan_launches = 0;
+  unsigned scan_seq = 0;
+  bool buckets_clean = false;
 };
 
 static int ensure (DevBuf &b, size_t bytes, hipStream_t stream, size_t keep_bytes = 0)
@@ -2097,12 +2121,11 @@ static Buckets make_buckets (const tjamd_counter *c)
 // forget every raw record: cursors and chunk counter to zero, chunk table to "unclaimed"
 static int clear_buckets (tjamd_counter *c)
 {
-  HIPCHK (hipMemsetAsync (c->d_cursors, 0, (TJ_P + 1) * sizeof (u32), c->stream));
-  HIPCHK (hipMemsetAsync (&c->d_ctr->n_null, 0, sizeof (u64), c->stream));
-  if (c->table.p && c->maxj) {
-    HIPCHK (hipMemsetAsync (c->table.p, 0xFF, (size_t) TJ_P * c->maxj * 4, c->stream));
-    hipLaunchKernelGGL (init_table_kernel, dim3 (1), dim3 (TJ_P), 0, c->stream, (u32 *) c->table.p, c->maxj, c->d_cursors + TJ_P);
+  if (!c->buckets_clean) {
+    hipLaunchKernelGGL (clear_buckets_kernel, dim3 (c->table.p && c->maxj ? 64 : 1), dim3 (256), 0, c->stream, c->d_cursors, &c->d_ctr->n_null,
+                        (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj);
     HIPCHK (hipGetLastError ());
+    c->buckets_clean = true;
   }
   c->n_raw_known = 0; c->bucket_bound = 0; c->chunk_bound = TJ_P; c->ch_shift = -1;
   return TJAMD_OK;
@@ -2150,7 +2173,7 @@ static int sync_counters (tjamd_counter *c)
     return set_err (TJAMD_ERR_CAPACITY, "raw record storage exhausted (%u of %u chunks handed out, fullest bucket %llu records): "
                     "raise TATAJUBA_AMD_BUCKET_SLACK (now %.1f) and scan again", c->h_cursors[TJ_P], c->pool_chunks, (unsigned long long) mx, c->slack);
   if (c->h_ctr->fix_overflow) return set_err (TJAMD_ERR_CAPACITY, "too many non-ACGTU tract candidates in one batch (%llu)",
-                                             (unsigned long long) c->h_ctr->n_fix);
+                                             (unsigned long long) std::max (c->h_ctr->lc[0].n_fix, c->h_ctr->lc[1].n_fix));
   c->n_raw_known = total - (long) c->h_ctr->n_null;
   c->bucket_bound = mx;
   c->chunk_bound = c->h_cursors[TJ_P];
@@ -2172,6 +2195,7 @@ static int ensure_buckets (tjamd_counter *c, u64 add, int grid)
   (void) grid;
   // one chunk per bucket is always claimed ahead of the cursor
   const u64 need_chunks = c->chunk_bound + (add + ch - 1) / ch + 2 * TJ_P;
+  c->buckets_clean = false;
   const u64 need_maxj = (c->bucket_bound + add + ch - 1) / ch + 3;      // worst case: everything in one bucket
   if (need_chunks >= TJ_NOCHUNK || need_maxj >= (1ull << 31)) return set_err (TJAMD_ERR_CAPACITY, "batch too large for the chunk table");
   int rc = ensure (c->pool, (size_t) need_chunks * ch * c->W * 8, c->stream, std::min<size_t> ((size_t) (c->chunk_bound * ch * c->W * 8), c->pool.cap));
@@ -2235,24 +2259,23 @@ extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t
   const uint8_t *seq = (const uint8_t *) d_stream;
   const Buckets BK = make_buckets (c);
   FixEntry *fix = (FixEntry *) c->fix.p;
-  HIPCHK (hipMemsetAsync (&c->d_ctr->work, 0, sizeof (u32), c->stream));
+  const int par = (int) (c->scan_seq++ & 1u);            // per-launch counters are double-buffered (DevCounters::lc)
   HIPCHK (hipEventRecord (c->ev_s0, c->stream));
   switch (c->W) {
     case 1:
-      hipLaunchKernelGGL (scan_bins_kernel<1>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP);
-      hipLaunchKernelGGL (nrun_fixup_bins_kernel<1>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP);
+      hipLaunchKernelGGL (scan_bins_kernel<1>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par);
+      hipLaunchKernelGGL (nrun_fixup_bins_kernel<1>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par);
       break;
     case 2:
-      hipLaunchKernelGGL (scan_bins_kernel<2>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP);
-      hipLaunchKernelGGL (nrun_fixup_bins_kernel<2>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP);
+      hipLaunchKernelGGL (scan_bins_kernel<2>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par);
+      hipLaunchKernelGGL (nrun_fixup_bins_kernel<2>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par);
       break;
     default:
-      hipLaunchKernelGGL (scan_bins_kernel<4>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP);
-      hipLaunchKernelGGL (nrun_fixup_bins_kernel<4>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP);
+      hipLaunchKernelGGL (scan_bins_kernel<4>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par);
+      hipLaunchKernelGGL (nrun_fixup_bins_kernel<4>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par);
       break;
   }
   HIPCHK (hipGetLastError ());
-  HIPCHK (hipMemsetAsync (&c->d_ctr->n_fix, 0, sizeof (u64), c->stream));
   HIPCHK (hipEventRecord (c->ev_s1, c->stream));
   c->scan_timed = true;
   c->last_scan_launches = 1;
@@ -2289,9 +2312,9 @@ extern "C" long tjamd_scan_host_located (tjamd_counter *c, const void *h_stream,
       hipMemsetAsync (c->d_lctr, 0, sizeof (DevCounters), c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy to device failed");
   const long n_tiles = (long) ((n_bytes + 4095) / 4096);
   hipLaunchKernelGGL (scan_list_kernel, dim3 ((unsigned) std::min<long> (n_tiles, 2048)), dim3 (256), 0, c->stream, (const uint8_t *) c->stage.p, (long) n_bytes,
-                      n_tiles, c->k, mprime, (u64 *) c->loc.p, (u64) bound, c->d_lctr, (FixEntry *) c->fix.p, (u32) TJ_FIX_CAP);
+                      n_tiles, c->k, mprime, (u64 *) c->loc.p, (u64) bound, c->d_lctr, (FixEntry *) c->fix.p, (u32) TJ_FIX_CAP, 0);
   hipLaunchKernelGGL (nrun_fixup_list_kernel, dim3 (64), dim3 (256), 0, c->stream, (const uint8_t *) c->stage.p, (long) n_bytes, c->k, mprime,
-                      (u64 *) c->loc.p, (u64) bound, c->d_lctr, (const FixEntry *) c->fix.p, (u32) TJ_FIX_CAP);
+                      (u64 *) c->loc.p, (u64) bound, c->d_lctr, (const FixEntry *) c->fix.p, (u32) TJ_FIX_CAP, 0);
   if (hipGetLastError () != hipSuccess) return -set_err (TJAMD_ERR_HIP, "located scan launch failed");
   if (hipMemcpyAsync (c->h_ctr, c->d_lctr, sizeof (DevCounters), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "located scan failed: %s", hipGetErrorString (hipGetLastError ()));
@@ -2495,7 +2518,7 @@ static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
 static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
 {
   int nbits = 6;
-  while (nbits < BS_MAXBITS && nbits < 1 + 4 * c->k && (24l << nbits) < n1) nbits++;
+  while (nbits < BS_MAXBITS && nbits < 1 + 4 * c->k && (48l << nbits) < n1) nbits++;   // ~24..48 records per bin: most of a wavefront's lanes busy
   nbits = std::min (nbits, 1 + 4 * c->k);
   const int nbins = 1 << nbits;
   const int log2t = cov_table_bits (n1);
@@ -2519,7 +2542,7 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
   hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n1, c->k, nbits, bins);
   hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, bins, nbins, binstart, c->bin_rank_max, c->d_fin);
   hipLaunchKernelGGL (bin_scatter_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins);
-  hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 8192)), dim3 (64 * BSI_WAVES), 0, c->stream,
+  hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 16384)), dim3 (64 * BSI_WAVES), 0, c->stream,
                       (const u64 *) c->alt.p, (u64 *) c->kept.p, (const u32 *) binstart, nbins, (const FinCounts *) c->d_fin, min_coverage,
                       ckeys, csums, log2t, binctx, tstart, tend);
   hipLaunchKernelGGL (bin_ctx_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, (const u32 *) binctx, nbins, binout, c->d_fin);
