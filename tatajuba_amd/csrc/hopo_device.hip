@@ -1003,13 +1003,19 @@ __global__ void init_table_kernel (u32 *table, u32 maxj, u32 *pool_next)
   if (b == 0) *pool_next = TJ_P;
 }
 
-// empty buckets: cursors 0, every bucket owns chunk b as its chunk 0, the rest of the table unclaimed, pool_next = TJ_P
-__global__ void clear_buckets_kernel (u32 *cursors, u64 *n_null, u32 *table, u32 maxj)
+// empty buckets: cursors 0, every bucket owns chunk b as its chunk 0, the rest of the table unclaimed, pool_next = TJ_P.
+// One workgroup per bucket; only the row entries the bucket can have claimed are rewritten (its records / chunk + the
+// one claimed ahead), unless the whole row is asked for.
+__global__ void clear_buckets_kernel (u32 *cursors, u64 *n_null, u32 *table, u32 maxj, int ch_shift)
 {
-  const u64 i0 = blockIdx.x * (u64) blockDim.x + threadIdx.x;
-  if (i0 < TJ_P) cursors[i0] = 0;
-  if (i0 == 0) { cursors[TJ_P] = TJ_P; *n_null = 0; }
-  if (table) for (u64 i = i0; i < (u64) TJ_P * maxj; i += (u64) gridDim.x * blockDim.x) table[i] = (i % maxj == 0) ? (u32) (i / maxj) : TJ_EMPTY;
+  const u32 b = blockIdx.x;
+  if (table) {
+    u32 used = maxj;
+    if (ch_shift >= 0) used = min (maxj, ((cursors[b] / TJ_CH0) >> ch_shift) + 3u);
+    for (u32 j = threadIdx.x; j < used; j += blockDim.x) table[(u64) b * maxj + j] = j ? TJ_EMPTY : b;
+  }
+  __syncthreads ();
+  if (threadIdx.x == 0) { cursors[b] = 0; if (b == 0) { cursors[TJ_P] = TJ_P; *n_null = 0; } }
 }
 
 // chunk table with a longer row
@@ -1811,15 +1817,32 @@ __global__ void ctx_write_kernel (long n1, const u32 *__restrict__ ctxpos, const
 
 // coverage: pooled 31-bit-truncated flanks weighted by count, largest pooled weight wins (reference
 // src/hopo_counter.c:419-438).  Open-addressing table in HBM; a slot holds key + 1, 0 = empty.
-__device__ __forceinline__ void cov_add (u32 key31, int w, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
+__device__ __forceinline__ void cov_add_from (u32 key31, u32 slot, int w, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
 {
   const u32 tmask = (1u << log2t) - 1u, stored = key31 + 1u;
-  u32 slot = (key31 * 2654435761u) >> (32 - log2t);
   for (u32 probe = 0; probe <= tmask; probe++) {
     const u32 old = atomicCAS (&keys[slot], 0u, stored);
     if (old == 0u || old == stored) { atomicAdd (&sums[slot], w); break; }
     slot = (slot + 1u) & tmask;
   }
+}
+
+__device__ __forceinline__ void cov_add (u32 key31, int w, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
+{
+  cov_add_from (key31, (key31 * 2654435761u) >> (32 - log2t), w, keys, sums, log2t);
+}
+
+// two keys at once: both compare-and-swaps are in flight together (the round trip to the memory-side atomics dominates)
+__device__ __forceinline__ void cov_add2 (u32 ka, u32 kb, int w, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
+{
+  const u32 tmask = (1u << log2t) - 1u, sa = ka + 1u, sb = kb + 1u;
+  u32 pa = (ka * 2654435761u) >> (32 - log2t), pb = (kb * 2654435761u) >> (32 - log2t);
+  const u32 oa = atomicCAS (&keys[pa], 0u, sa), ob = atomicCAS (&keys[pb], 0u, sb);
+  if (oa == 0u || oa == sa) atomicAdd (&sums[pa], w);
+  else cov_add_from (ka, (pa + 1u) & tmask, w, keys, sums, log2t);
+  // (if both keys are equal and met an empty slot, the second CAS has seen the first one's key: still one slot)
+  if (ob == 0u || ob == sb) atomicAdd (&sums[pb], w);
+  else cov_add_from (kb, (pb + 1u) & tmask, w, keys, sums, log2t);
 }
 
 __global__ void cov_insert_kernel (const u64 *__restrict__ kept, long n1, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
@@ -1884,8 +1907,7 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
       if (t < s) {
         const u64 a0 = R[3 * t], a1 = R[3 * t + 1], am = R[3 * t + 2];
         const int w = meta_count (am);
-        cov_add ((u32) (a0 & 0x7FFFFFFFull), w, cov_keys, cov_sums, log2t);
-        cov_add ((u32) (a1 & 0x7FFFFFFFull), w, cov_keys, cov_sums, log2t);
+        cov_add2 ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_keys, cov_sums, log2t);
         u32 rank = 0, ctx_before = 0, ctx_size = 0;
         int depth = 0;
         for (u32 j = 0; j < s; j++) {
@@ -2122,8 +2144,8 @@ static Buckets make_buckets (const tjamd_counter *c)
 static int clear_buckets (tjamd_counter *c)
 {
   if (!c->buckets_clean) {
-    hipLaunchKernelGGL (clear_buckets_kernel, dim3 (c->table.p && c->maxj ? 64 : 1), dim3 (256), 0, c->stream, c->d_cursors, &c->d_ctr->n_null,
-                        (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj);
+    hipLaunchKernelGGL (clear_buckets_kernel, dim3 (TJ_P), dim3 (256), 0, c->stream, c->d_cursors, &c->d_ctr->n_null,
+                        (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj, c->ch_shift);
     HIPCHK (hipGetLastError ());
     c->buckets_clean = true;
   }
@@ -2450,7 +2472,7 @@ static unsigned grid_for (long n) { return (unsigned) std::max<long> (1, std::mi
 
 // ---- finalise steps 3-4 + coverage, two ways --------------------------------------------------------------------
 
-static int cov_table_bits (long n1) { int b = 10; while ((1l << b) < 8 * n1 && b < 31) b++; return b; }
+static int cov_table_bits (long n1) { int b = 10; while ((1l << b) < 4 * n1 && b < 31) b++; return b; }   // 2 n1 entries at most: half full
 
 // radix path: stable LSD sort, then heads / scans / decisions as separate kernels (any bin occupancy, any size)
 static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
