@@ -1100,7 +1100,7 @@ struct Agg1Lds
 };
 
 __global__ __launch_bounds__ (AG_BLOCK)
-void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
 {
   __shared__ Agg1Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1110,6 +1110,11 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
   if (n) for (u32 j = (u32) tid; j <= chunk_of_pos (BK, n - 1u) && j < AG_NCH; j += AG_BLOCK) L.chunk[j] = bucket_chunk_id (BK, bkt, j, false, nullptr);
   auto chunk_id = [&] (u32 j) { return j < AG_NCH ? L.chunk[j] : bucket_chunk_id (BK, bkt, j, false, nullptr); };
 
+  // records that do not fit a round's table go to the same place in a second pool (`ovf`) and are read from there in
+  // the next round, whose own leftovers go back to the first pool: no wave ever writes where another may still read,
+  // so the waves of a round run free of each other (no barrier in the record loop).
+  const u64 *src = BK.pool;
+  u64 *dst = ovf;
   ASTAMP_DECL;
   while (n > 0) {
     ASTAMP (0);
@@ -1137,7 +1142,7 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
       for (int r = 0; r < AG1_R; r++) {
         const u32 idx = b0 + (u32) r * AG_BLOCK + (u32) tid;
         const bool hi = idx >= bound;
-        if (idx < n && (hi ? c1 : c0) != TJ_NOCHUNK) { vn |= 1u << r; wn[r] = BK.pool[(hi ? off1 : off0) + idx]; }
+        if (idx < n && (hi ? c1 : c0) != TJ_NOCHUNK) { vn |= 1u << r; wn[r] = src[(hi ? off1 : off0) + idx]; }
       }
     };
     fetch (0u);
@@ -1155,10 +1160,6 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
       const u32 valid = vn;
       fetch (b0 + AG_BLOCK * AG1_R);
       ASTAMP (3);
-      // One barrier per round: every lane holds its records of this round in registers, so the leftovers written below
-      // (in place, from the front of the bucket: fewer than the records consumed so far) never land on a record
-      // somebody still has to read.  Closing the table needs no barrier: see the slot protocol.
-      lds_barrier ();
       ASTAMP (4);
 #if defined(TJ_EXP_AGG) && TJ_EXP_AGG == 1      // experiment: loads only
       { u64 acc = 0;
@@ -1215,7 +1216,7 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
           if (left) {                                   // back to the front of the bucket (chunk id cached per lane)
             const u32 o = atomicAdd (&L.n_ovf, 1u);
             const u32 j = chunk_of_pos (BK, o), oc = chunk_id (j);
-            if (oc != TJ_NOCHUNK) BK.pool[(((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift))] = cur;
+            if (oc != TJ_NOCHUNK) dst[(((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift))] = cur;
           }
           if (adv) {
             r++; probes = 0;
@@ -1269,6 +1270,7 @@ void aggregate1_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
     __threadfence_block ();
     __syncthreads ();
     n = L.n_ovf;
+    { const u64 *t = src; src = dst; dst = (u64 *) t; }
     __syncthreads ();
     ASTAMP (7);
   }
@@ -2033,7 +2035,7 @@ struct tjamd_counter
   long n_raw_known = 0;       // exact after the last synchronisation
   long n_undefined = 0;
   double slack = 1.0;
-  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov, bins, binstart, binctx;
+  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov, bins, binstart, binctx, ovf;
   u32 bin_rank_max = BS_RANK_MAX;
   FinCounts *d_fin = nullptr, *h_fin = nullptr;
   long n_kept = 0; int n_idx = 0, coverage = 0, status = -1;
@@ -2104,7 +2106,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   (void) hipSetDevice (c->device);
   (void) hipStreamSynchronize (c->stream);
   DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
-                   &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx};
+                   &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx, &c->ovf};
   for (DevBuf *b : all) release (*b);
   if (c->d_ctr) (void) hipFree (c->d_ctr);
   if (c->d_lctr) (void) hipFree (c->d_lctr);
@@ -2591,12 +2593,13 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
 
   // steps 1-2: per-bucket hash aggregation + filter (reference :351-374).  Distinct keys <= raw records.
   rc = ensure (c->kept, (size_t) n * 24, c->stream);
+  if (!rc && c->W == 1) rc = ensure (c->ovf, c->pool.cap, c->stream);   // second pool for the aggregation's leftover rounds
   if (rc) return rc;
   HIPCHK (hipEventRecord (c->ev_f0, c->stream));
   HIPCHK (hipMemsetAsync (c->d_fin, 0, sizeof (FinCounts), c->stream));
   const Buckets BK = make_buckets (c);
   switch (c->W) {
-    case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
+    case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
     case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
     default: hipLaunchKernelGGL (aggregate_kernel<4>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
   }

@@ -288,6 +288,15 @@ def test_finalise_skewed_bins():
         assert st == 0 and n > (1000 if k == 20 else 10)
 
 
+@pytest.mark.parametrize("k,m", [(10, 3), (20, 3), (31, 4)])
+def test_finalise_many_distinct_keys_leftover_rounds(k, m):
+    # a large genome at low depth: several thousand distinct keys per hash bucket, more than one round of the
+    # aggregation's LDS table holds (the records of the keys that do not fit go round again)
+    s = tj.synth_stream(700000, 150, 40_000_000)
+    st, n = check_finalise([s], k, m, 0, 0)
+    assert st == 0 and n > 150000
+
+
 def test_finalise_statuses_and_count_semantics():
     assert check_finalise([np.frombuffer(b"ACGT\n", np.uint8)], 3, 3, 1, 5)[0] == 1
     assert check_finalise([np.frombuffer(b"CCGAAAAGAT\n", np.uint8)], 3, 3, 1, 0)[0] == 2
