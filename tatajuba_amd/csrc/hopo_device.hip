@@ -1086,7 +1086,7 @@ __device__ __forceinline__ bool agg_insert (AggLds &L, u64 c0, u64 c1, u32 k2, u
 // ---- W = 1 (k <= 12): the whole reduction key is the record word without its strand flag, so one 64-bit LDS
 // compare-and-swap per probe decides "new key / same key / other key" -- no tag, no publish step, no key read-back.
 #define AG1_S        8192
-#define AG1_CLOSE_AT 3584                // at most one more key per lane (1024) gets in: the table stays below 60 % full
+#define AG1_CLOSE_AT 4864                // typical overshoot: a few keys; worst case one per lane (1024): 72 % full
 #define AG1_R        4                   // records in flight per lane
 #define AG1_MARK     (~0ull)             // a key is at most 59 bits
 
@@ -1278,100 +1278,130 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
 }
 
 // ---- W = 2 (k <= 28): word 0 of the record is never 0 and leaves bit 63 free, so it doubles as the slot's claim word:
-// compare-and-swap 0 -> (word0 | PENDING), write word 1, then store word0 (release).  A prober that meets its own
-// word0 with PENDING set looks again; with it clear the second word is there to compare.
+// compare-and-swap 0 -> (word0 | PENDING), write word 1, then store word0.  A prober that meets its own word0 with
+// PENDING set looks again; with it clear the second word is there to compare.  Same structure as aggregate1_kernel:
+// records in flight per lane, read-first probing (a bucket holds each key many times), a closed table MARKs the free
+// slot at the end of a probe chain so that a key is in the table for all of its records or for none, leftovers go to
+// the second pool, no barrier in the record loop.
 #define AG2_S        4096
-#define AG2_CLOSE_AT 1280                // + 1024 of the batch in flight: below 60 % full
+#define AG2_CLOSE_AT 2560                // typical overshoot: a few keys; worst case one per lane (1024): 87 % full
+#define AG2_R        2                   // records in flight per lane
 #define AG2_PENDING  (1ull << 63)
+#define AG2_MARK     (1ull << 63)        // PENDING without a word0 (word0 always has bit 0 set)
 
 struct Agg2Lds
 {
   u64 k0[AG2_S], k1[AG2_S];
-  u32 cf[AG2_S], cr[AG2_S];
-  u32 n_claimed, n_ovf, closed[2], total;
+  u32 cnt[2 * AG2_S];                   // per slot: forward / reverse strand
+  u32 chunk[AG_NCH];
+  u32 n_claimed, n_ovf, total;
   u32 wsum[AG_BLOCK / 64];
 };
 
 __global__ __launch_bounds__ (AG_BLOCK)
-void aggregate2_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
 {
   __shared__ Agg2Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 bkt = blockIdx.x;
   u32 n = BK.cursors[bkt];
   const u64 m56 = (1ull << 56) - 1ull, fmask = ~(3ull << 61);
+  if (n) for (u32 j = (u32) tid; j <= chunk_of_pos (BK, n - 1u) && j < AG_NCH; j += AG_BLOCK) L.chunk[j] = bucket_chunk_id (BK, bkt, j, false, nullptr);
+  auto chunk_id = [&] (u32 j) { return j < AG_NCH ? L.chunk[j] : bucket_chunk_id (BK, bkt, j, false, nullptr); };
+  const u64 *src = BK.pool;
+  u64 *dst = ovf;
 
   while (n > 0) {
-    for (int i = tid; i < AG2_S; i += AG_BLOCK) { L.k0[i] = 0; L.cf[i] = 0; L.cr[i] = 0; }
-    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.closed[0] = L.closed[1] = 0; }
+    for (int i = tid; i < AG2_S; i += AG_BLOCK) { L.k0[i] = 0; L.cnt[2 * i] = 0; L.cnt[2 * i + 1] = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; }
     __syncthreads ();
 
-    u64 wn0 = 0, wn1 = 0;
-    bool vn = false;
-    u32 cj = TJ_EMPTY, cc = TJ_NOCHUNK, oj = TJ_EMPTY, oc = TJ_NOCHUNK;
-    auto fetch = [&] (u32 idx) {
-      vn = false;
-      if (idx < n) {
-        const u32 j = chunk_of_pos (BK, idx);
-        if (j != cj) { cj = j; cc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
-        if (cc != TJ_NOCHUNK) {
-          const u64 at = (((u64) cc * TJ_CH0) << BK.ch_shift) + (idx - ((j * TJ_CH0) << BK.ch_shift));
-          vn = true; wn0 = BK.pool[2 * at]; wn1 = BK.pool[2 * at + 1];
+    u64 wn[2 * AG2_R];
+    u32 vn = 0;
+    auto fetch = [&] (u32 b0) {                         // see aggregate1_kernel: a round lies in at most two chunks
+      vn = 0;
+#pragma unroll
+      for (int r = 0; r < 2 * AG2_R; r++) wn[r] = 0;
+      if (b0 >= n) return;
+      const u32 ch = (u32) TJ_CH0 << BK.ch_shift;
+      const u32 j0 = chunk_of_pos (BK, b0), bound = (j0 + 1u) * ch;
+      const u32 c0 = chunk_id (j0), c1 = (bound < n) ? chunk_id (j0 + 1u) : TJ_NOCHUNK;
+      const u64 off0 = (u64) c0 * ch - (u64) j0 * ch, off1 = (u64) c1 * ch - (u64) bound;
+#pragma unroll
+      for (int r = 0; r < AG2_R; r++) {
+        const u32 idx = b0 + (u32) r * AG_BLOCK + (u32) tid;
+        const bool hi = idx >= bound;
+        if (idx < n && (hi ? c1 : c0) != TJ_NOCHUNK) {
+          const ulonglong2 v = *reinterpret_cast<const ulonglong2 *> (src + 2 * ((hi ? off1 : off0) + idx));
+          vn |= 1u << r; wn[2 * r] = v.x; wn[2 * r + 1] = v.y;
         }
       }
     };
-    fetch ((u32) tid);
-    u32 par = 0;
-    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK, par ^= 1u) {
-      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's record has arrived (fetched one batch ago)
-      const u64 w0 = wn0, w1 = wn1;
-      const bool valid = vn;
-      fetch (b0 + AG_BLOCK + tid);
-      // two barriers per batch: see aggregate1_kernel
-      if (tid == 0) L.closed[par] = (L.n_claimed > AG2_CLOSE_AT) ? 1u : 0u;
-      lds_barrier ();
-      const bool closed = L.closed[par] != 0u;
-      if (valid && ((w1 >> 61) & 3ull) != 3ull) {
-        const u64 key1 = w1 & fmask;
-        u32 h = (u32) w0 ^ __builtin_amdgcn_alignbit ((u32) (w0 >> 32), (u32) (w0 >> 32), 19) ^
-                __builtin_amdgcn_alignbit ((u32) key1, (u32) key1, 11) ^ __builtin_amdgcn_alignbit ((u32) (key1 >> 32), (u32) (key1 >> 32), 25);
-        h *= 0x9E3779B1u; h ^= h >> 15;
-        u32 slot = h & (AG2_S - 1);
-        bool done = false;
-        for (u32 probes = 0; probes < AG2_S && !done;) {
-          u64 old;
-          if (!closed) {
-            unsigned long long expected = 0ull;
-            __hip_atomic_compare_exchange_strong ((unsigned long long *) &L.k0[slot], &expected, (unsigned long long) (w0 | AG2_PENDING),
-                                                  __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            old = expected;
-            if (old == 0ull) {                          // claimed: publish the second word, then the first
-              L.k1[slot] = key1;
-              atomicAdd (&L.n_claimed, 1u);
-              __hip_atomic_store ((unsigned long long *) &L.k0[slot], (unsigned long long) w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-              atomicAdd ((w1 >> 62) & 1ull ? &L.cr[slot] : &L.cf[slot], 1u);
-              done = true;
-              break;
+    fetch (0u);
+    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK * AG2_R) {
+      asm volatile ("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]) :: "memory");
+      static_assert (AG2_R == 2, "asm operand list");
+      u64 w[2 * AG2_R];
+#pragma unroll
+      for (int r = 0; r < 2 * AG2_R; r++) w[r] = wn[r];
+      const u32 valid = vn;
+      fetch (b0 + AG_BLOCK * AG2_R);
+      {
+        u32 r = 0, probes = 0;
+        u64 w0 = w[0], w1 = w[1];
+        auto home = [] (u64 a, u64 b) {
+          const u64 key1 = b & ~(3ull << 61);
+          u32 h = (u32) a ^ __builtin_amdgcn_alignbit ((u32) (a >> 32), (u32) (a >> 32), 19) ^
+                  __builtin_amdgcn_alignbit ((u32) key1, (u32) key1, 11) ^ __builtin_amdgcn_alignbit ((u32) (key1 >> 32), (u32) (key1 >> 32), 25);
+          h *= 0x9E3779B1u; h ^= h >> 15;
+          return h & (AG2_S - 1);
+        };
+        u32 slot = home (w0, w1);
+        while (r < AG2_R) {
+          bool adv = false, left = false;
+          if (!((valid >> r) & 1u) || ((w1 >> 61) & 3ull) == 3ull) adv = true;
+          else {
+            const u64 key1 = w1 & fmask;
+            const u32 strand = (u32) (w1 >> 62) & 1u;
+            const u64 a = __hip_atomic_load ((unsigned long long *) &L.k0[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (a == w0) {
+              if (L.k1[slot] == key1) { atomicAdd (&L.cnt[2 * slot + strand], 1u); adv = true; }
+              else if (++probes >= AG2_S) { left = true; adv = true; }
+              else slot = (slot + 1u) & (AG2_S - 1);
             }
-            if (old == (w0 | AG2_PENDING)) continue;    // same first word, owner still writing: look again
+            else if (a == AG2_MARK) { left = true; adv = true; }
+            else if (a == 0ull) {                       // the chain ends here: claim the slot, or MARK it if the table is closed
+              const bool closed = __hip_atomic_load (&L.n_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > AG2_CLOSE_AT;
+              unsigned long long expected = 0ull;
+              __hip_atomic_compare_exchange_strong ((unsigned long long *) &L.k0[slot], &expected, closed ? AG2_MARK : (unsigned long long) (w0 | AG2_PENDING),
+                                                    __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (expected == 0ull) {
+                if (closed) left = true;
+                else {                                  // claimed: publish the second word, then the first
+                  L.k1[slot] = key1;
+                  atomicAdd (&L.n_claimed, 1u);
+                  __hip_atomic_store ((unsigned long long *) &L.k0[slot], (unsigned long long) w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  atomicAdd (&L.cnt[2 * slot + strand], 1u);
+                }
+                adv = true;
+              }                                         // else somebody else took the slot: look at it again
+            }
+            else if (a != (w0 | AG2_PENDING)) {         // another key (PENDING with our word0: its owner is still writing, look again)
+              if (++probes >= AG2_S) { left = true; adv = true; }
+              else slot = (slot + 1u) & (AG2_S - 1);
+            }
           }
-          else old = __hip_atomic_load ((unsigned long long *) &L.k0[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (old == w0 && L.k1[slot] == key1) { atomicAdd ((w1 >> 62) & 1ull ? &L.cr[slot] : &L.cf[slot], 1u); done = true; break; }
-          if (old == 0ull) break;                       // closed table, key absent
-          slot = (slot + 1u) & (AG2_S - 1);
-          probes++;
-        }
-        if (!done) {                                    // back to the front of the bucket (chunk id cached per lane)
-          const u32 o = atomicAdd (&L.n_ovf, 1u);
-          const u32 j = chunk_of_pos (BK, o);
-          if (j != oj) { oj = j; oc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
-          if (oc != TJ_NOCHUNK) {
-            const u64 at = (((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift));
-            BK.pool[2 * at] = w0; BK.pool[2 * at + 1] = w1;
+          if (left) {
+            const u32 o = atomicAdd (&L.n_ovf, 1u);
+            const u32 j = chunk_of_pos (BK, o), oc = chunk_id (j);
+            if (oc != TJ_NOCHUNK) {
+              const u64 at = (((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift));
+              dst[2 * at] = w0; dst[2 * at + 1] = w1;
+            }
           }
+          if (adv) { r++; probes = 0; w0 = w[2]; w1 = w[3]; slot = home (w0, w1); }
         }
       }
-      lds_barrier ();
     }
     __syncthreads ();
 
@@ -1381,8 +1411,8 @@ void aggregate2_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
     for (int r = 0; r < AG2_S / AG_BLOCK; r++) {
       const int slot = tid + r * AG_BLOCK;
       metas[r] = 0;
-      if (L.k0[slot]) {
-        const u32 cf = L.cf[slot], cr = L.cr[slot];
+      if (L.k0[slot] && L.k0[slot] != AG2_MARK) {
+        const u32 cf = L.cnt[2 * slot], cr = L.cnt[2 * slot + 1];
         const u64 flag = (cf ? 1ull : 0ull) | (cr ? 2ull : 0ull);
         const u64 cnt = ((u64) cf + (u64) cr) & 0xFFFFFull;
         const int scnt = (cnt & 0x80000ull) ? (int) cnt - 0x100000 : (int) cnt;
@@ -1414,6 +1444,7 @@ void aggregate2_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ 
     __threadfence_block ();
     __syncthreads ();
     n = L.n_ovf;
+    { const u64 *t = src; src = dst; dst = (u64 *) t; }
     __syncthreads ();
   }
 }
@@ -2593,14 +2624,14 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
 
   // steps 1-2: per-bucket hash aggregation + filter (reference :351-374).  Distinct keys <= raw records.
   rc = ensure (c->kept, (size_t) n * 24, c->stream);
-  if (!rc && c->W == 1) rc = ensure (c->ovf, c->pool.cap, c->stream);   // second pool for the aggregation's leftover rounds
+  if (!rc && c->W <= 2) rc = ensure (c->ovf, c->pool.cap, c->stream);   // second pool for the aggregation's leftover rounds
   if (rc) return rc;
   HIPCHK (hipEventRecord (c->ev_f0, c->stream));
   HIPCHK (hipMemsetAsync (c->d_fin, 0, sizeof (FinCounts), c->stream));
   const Buckets BK = make_buckets (c);
   switch (c->W) {
     case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
-    case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
+    case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
     default: hipLaunchKernelGGL (aggregate_kernel<4>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
   }
   HIPCHK (hipGetLastError ());
