@@ -73,12 +73,12 @@ struct TileLds
   static constexpr int MAXCAND = TILE / CANDDIV;         // tracts have >= 2 bases: one candidate per 2 bytes at most
                                                          // (CANDDIV 1: the located kernel's all-monomers mode)
   static constexpr int NLOAD = (NCHUNK + BLOCK - 1) / BLOCK;
+  static constexpr int NRAW = NCHUNK + NLOAD * (BLOCK / 64);   // landing zone: the chunks + per wave and load, the chunk in front of its first one
   u32 code[CODEW];
   u32 start[MASKW];
   u32 sent[MASKW];
   u32 inval[MASKW];
   unsigned short cand[MAXCAND];
-  unsigned short fl[NCHUNK + 4];                         // per chunk: first byte | last byte << 8
   u32 ncand;
   u32 grp[2];                                            // first tile of the current / next group of this workgroup
   u32 odd[2];                                            // per tile parity: some byte of the tile is neither ACGT nor '\n'
@@ -387,7 +387,10 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
       const int c = tid + i * BLOCK;
-      if (c < G::NCHUNK) issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, &raw[c - (tid & 63)]);
+      if (c < G::NCHUNK) {
+        issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, &raw[c - (tid & 63)]);
+        if ((tid & 63) == 0) issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * (c - 1), &raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)]);
+      }
     }
   }
 
@@ -417,9 +420,14 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
         }
         const u32 w[4] = {v.x, v.y, v.z, v.w};
         u32 code32 = 0, st16 = 0, se16 = 0, iv16 = 0, bad = 0;
-        // The byte in front of the chunk belongs to another lane: the chunk's first run-start bit is left 0 here and
-        // patched in phase 2 from the first / last bytes every chunk leaves in T.fl.
-        u32 prevw = w[0] << 24;
+        // The byte in front of the chunk is the last byte of the lane before (one DPP move); the wave's first lane
+        // finds it in the extra chunk its wave loaded for the purpose.
+        u32 prevw = (u32) __builtin_amdgcn_update_dpp (0, (int) v.w, 0x138, 0xF, 0xF, false);      // wave_shr:1
+        if ((tid & 63) == 0) {
+          prevw = raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)].w;
+          if (!interior) prevw = stream_byte (seq, n_bytes, g0 + 16l * c - 1) << 24;
+        }
+        const u32 prev0 = prevw >> 24;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           u32 c8, s4, e4, b;
@@ -429,7 +437,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
         }
         if (__builtin_expect (bad != 0u, 0)) {          // lower case, U, N, anything else: exact classification
           T.odd[tpar] = 1u;
-          u32 prev = w[0] & 0xFFu;
+          u32 prev = prev0;
           code32 = st16 = se16 = iv16 = 0;
           for (int j = 0; j < 4; j++) {
             u32 c8, s4, e4, i4;
@@ -442,7 +450,6 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
         reinterpret_cast<unsigned short *> (T.start)[c] = (unsigned short) st16;
         reinterpret_cast<unsigned short *> (T.sent)[c] = (unsigned short) se16;
         reinterpret_cast<unsigned short *> (T.inval)[c] = (unsigned short) (iv16 | se16);
-        T.fl[c] = (unsigned short) ((w[0] & 0xFFu) | ((w[3] >> 24) << 8));
       }
     }
     sink.tick ();
@@ -454,7 +461,10 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
 #pragma unroll
         for (int i = 0; i < G::NLOAD; i++) {
           const int c = tid + i * BLOCK;
-          if (c < G::NCHUNK) issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, &raw[c - (tid & 63)]);
+          if (c < G::NCHUNK) {
+            issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, &raw[c - (tid & 63)]);
+            if ((tid & 63) == 0) issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * (c - 1), &raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)]);
+          }
         }
       }
     }
@@ -467,19 +477,8 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
 
     // ---- phase 2: candidate tract starts among this lane's 16 positions ------------------------------------
     {
-      const int p0 = TJ_HL + 16 * tid, c0 = p0 >> 4;
-      u64 S = bits64 (T.start, p0);
-      // first position of a chunk: run start iff its byte differs from the last byte of the chunk before
-      u32 f[5];
-#pragma unroll
-      for (int i = 0; i < 5; i++) f[i] = T.fl[c0 - 1 + i];
-#pragma unroll
-      for (int i = 0; i < 4; i++) S |= (u64) ((f[i + 1] & 0xFFu) != (f[i] >> 8)) << (16 * i);
-      if (S & 1ull) reinterpret_cast<unsigned short *> (T.start)[c0] |= 1;          // patch the plane for phase 3
-      if (tid < TJ_HR / 16) {                           // ... and the right halo's chunks, which no lane owns
-        const int ch = (TJ_HL + TILE) / 16 + tid;
-        if ((T.fl[ch] & 0xFFu) != (u32) (T.fl[ch - 1] >> 8)) reinterpret_cast<unsigned short *> (T.start)[ch] |= 1;
-      }
+      const int p0 = TJ_HL + 16 * tid;
+      const u64 S = bits64 (T.start, p0);
       u32 cand = (u32) S & 0xFFFFu;
       if (mprime <= 0) cand &= (u32) (S >> 1);                      // monomer mode: the next position starts a run too
       for (int j = 1; j < mprime; j++) cand &= ~(u32) (S >> j);     // next m'-1 positions continue the run
@@ -640,7 +639,7 @@ void scan_list_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
                        u64 *__restrict__ out, u64 cap, DevCounters *ctr, FixEntry *fix, u32 fix_cap, int par)
 {
   __shared__ TileLds<256, 4096, 1> T;
-  __shared__ uint4 raw[TileLds<256, 4096, 1>::NCHUNK];
+  __shared__ uint4 raw[TileLds<256, 4096, 1>::NRAW];
   ListSink sink = {out, cap, ctr};
   scan_tiles<256, 4096, 1> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap, par);
 }
@@ -945,7 +944,7 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
                        Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap, int par)
 {
   __shared__ TileLds<TJ_SB_BLOCK, TJ_SB_TILE> T;
-  __shared__ uint4 raw[TileLds<TJ_SB_BLOCK, TJ_SB_TILE>::NCHUNK];
+  __shared__ uint4 raw[TileLds<TJ_SB_BLOCK, TJ_SB_TILE>::NRAW];
   __shared__ StageLds<W> SL;
   StageSink<W, TJ_SB_BLOCK> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
   sink.start ();
