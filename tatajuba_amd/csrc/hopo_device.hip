@@ -102,6 +102,10 @@ struct DevCounters
 
 struct FixEntry { long long pos; long long len; };
 
+// counts of the finalise step (device block read back by the host)
+struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow, sort_fallback, pad; };
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
 
@@ -1005,7 +1009,7 @@ __global__ void init_table_kernel (u32 *table, u32 maxj, u32 *pool_next)
 // empty buckets: cursors 0, every bucket owns chunk b as its chunk 0, the rest of the table unclaimed, pool_next = TJ_P.
 // One workgroup per bucket; only the row entries the bucket can have claimed are rewritten (its records / chunk + the
 // one claimed ahead), unless the whole row is asked for.
-__global__ void clear_buckets_kernel (u32 *cursors, u64 *n_null, u32 *table, u32 maxj, int ch_shift)
+__global__ void clear_buckets_kernel (u32 *cursors, u64 *n_null, u32 *table, u32 maxj, int ch_shift, FinCounts *fin, u32 *bins, int nbins)
 {
   const u32 b = blockIdx.x;
   if (table) {
@@ -1013,8 +1017,9 @@ __global__ void clear_buckets_kernel (u32 *cursors, u64 *n_null, u32 *table, u32
     if (ch_shift >= 0) used = min (maxj, ((cursors[b] / TJ_CH0) >> ch_shift) + 3u);
     for (u32 j = threadIdx.x; j < used; j += blockDim.x) table[(u64) b * maxj + j] = j ? TJ_EMPTY : b;
   }
+  if (bins) for (int i = (int) (b * blockDim.x + threadIdx.x); i < nbins; i += (int) (gridDim.x * blockDim.x)) bins[i] = 0;
   __syncthreads ();
-  if (threadIdx.x == 0) { cursors[b] = 0; if (b == 0) { cursors[TJ_P] = TJ_P; *n_null = 0; } }
+  if (threadIdx.x == 0) { cursors[b] = 0; if (b == 0) { cursors[TJ_P] = TJ_P; *n_null = 0; fin->n_kept = 0; fin->overflow = 0; } }
 }
 
 // chunk table with a longer row
@@ -1037,7 +1042,6 @@ __global__ void table_relayout_kernel (const u32 *__restrict__ old, u32 old_maxj
 #define AG_BLOCK    1024
 #define AG_NCH      512                 // chunk ids of a bucket cached in LDS (longer buckets look the rest up in the table)
 
-struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow, sort_fallback, pad; };
 
 struct AggLds
 {
@@ -1684,8 +1688,9 @@ __device__ __forceinline__ bool record_before (u64 a0, u64 a1, u64 am, u32 ai, u
 }
 
 __global__ __launch_bounds__ (256)
-void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32 *__restrict__ bins)
-{
+void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32 *__restrict__ bins, uint4 *__restrict__ cov, long cov_vec)
+{ // (also empties the coverage table, which the sort pass three launches later fills: 16 bytes per store)
+  for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < cov_vec; i += (long) gridDim.x * 256) cov[i] = make_uint4 (0, 0, 0, 0);
   for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < n; i += (long) gridDim.x * 256) {
     const u64 *p = in + 3 * i;
     atomicAdd (&bins[bin_of_record (p[0], p[1], p[2], k, nbits)], 1u);
@@ -1729,7 +1734,7 @@ void bin_scan_kernel (u32 *__restrict__ bins, int nbins, u32 *__restrict__ binst
   __shared__ WgScanLds L;
   u32 vmax;
   const u32 total = wg_exclusive_scan (bins, nbins, binstart, bins, L, vmax);
-  if (threadIdx.x == 0) { binstart[nbins] = total; if (vmax > rank_max) fin->sort_fallback = 1u; }
+  if (threadIdx.x == 0) { binstart[nbins] = total; fin->sort_fallback = vmax > rank_max ? 1u : 0u; }
 }
 
 __global__ __launch_bounds__ (256)
@@ -2050,6 +2055,10 @@ struct DevBuf
   size_t cap = 0;
 };
 
+// everything the host reads back: one device block, one pinned mirror
+// (each part on cache lines of its own: the scan's workgroups hammer ctr and cursors with atomics)
+struct DevState { alignas (256) DevCounters ctr; alignas (256) FinCounts fin; alignas (256) u32 cursors[TJ_P + 1]; alignas (256) u32 pad[4]; };
+
 struct tjamd_counter
 {
   int device = 0, k = 0, W = 4, n_cu = 256;
@@ -2063,11 +2072,14 @@ struct tjamd_counter
   u64 bucket_bound = 0;       // upper bound of the fullest bucket (exact after a synchronisation)
   u64 chunk_bound = 0;        // upper bound of the chunks handed out
   long n_raw_known = 0;       // exact after the last synchronisation
+  u64 raw_bound = 0;          // upper bound of the raw records in the buckets (exact after a synchronisation)
   long n_undefined = 0;
   double slack = 1.0;
   DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov, bins, binstart, binctx, ovf;
   u32 bin_rank_max = BS_RANK_MAX;
   FinCounts *d_fin = nullptr, *h_fin = nullptr;
+  struct DevState *d_state = nullptr, *h_state = nullptr;   // ctr, fin and cursors live in one block: one copy brings all three to the host
+  bool bins_zeroed = false;
   long n_kept = 0; int n_idx = 0, coverage = 0, status = -1;
   hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_f0 = nullptr, ev_f1 = nullptr;
   bool scan_timed = false, fin_timed = false;
@@ -2114,16 +2126,14 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   if (sl && atof (sl) >= 1.0) c->slack = atof (sl);
   HIPCHK_NULL (hipStreamCreateWithFlags (&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
-  HIPCHK_NULL (hipMalloc ((void **) &c->d_ctr, sizeof (DevCounters)));
+  HIPCHK_NULL (hipMalloc ((void **) &c->d_state, sizeof (DevState)));
   HIPCHK_NULL (hipMalloc ((void **) &c->d_lctr, sizeof (DevCounters)));
-  HIPCHK_NULL (hipMalloc ((void **) &c->d_fin, sizeof (FinCounts)));
-  HIPCHK_NULL (hipMalloc ((void **) &c->d_cursors, (TJ_P + 1) * sizeof (u32)));
-  HIPCHK_NULL (hipHostMalloc ((void **) &c->h_ctr, sizeof (DevCounters), hipHostMallocDefault));
-  HIPCHK_NULL (hipHostMalloc ((void **) &c->h_fin, sizeof (FinCounts), hipHostMallocDefault));
-  HIPCHK_NULL (hipHostMalloc ((void **) &c->h_cursors, (TJ_P + 1) * sizeof (u32), hipHostMallocDefault));
-  HIPCHK_NULL (hipMemsetAsync (c->d_ctr, 0, sizeof (DevCounters), c->stream));
+  HIPCHK_NULL (hipHostMalloc ((void **) &c->h_state, sizeof (DevState), hipHostMallocDefault));
+  c->d_ctr = &c->d_state->ctr; c->d_fin = &c->d_state->fin; c->d_cursors = c->d_state->cursors;
+  c->h_ctr = &c->h_state->ctr; c->h_fin = &c->h_state->fin; c->h_cursors = c->h_state->cursors;
+  memset (c->h_state, 0, sizeof (DevState));
+  HIPCHK_NULL (hipMemsetAsync (c->d_state, 0, sizeof (DevState), c->stream));
   HIPCHK_NULL (hipMemsetAsync (c->d_lctr, 0, sizeof (DevCounters), c->stream));
-  HIPCHK_NULL (hipMemsetAsync (c->d_cursors, 0, (TJ_P + 1) * sizeof (u32), c->stream));
   HIPCHK_NULL (hipEventCreate (&c->ev_s0)); HIPCHK_NULL (hipEventCreate (&c->ev_s1));
   HIPCHK_NULL (hipEventCreate (&c->ev_f0)); HIPCHK_NULL (hipEventCreate (&c->ev_f1));
   HIPCHK_NULL (hipStreamSynchronize (c->stream));
@@ -2138,13 +2148,9 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
                    &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx, &c->ovf};
   for (DevBuf *b : all) release (*b);
-  if (c->d_ctr) (void) hipFree (c->d_ctr);
+  if (c->d_state) (void) hipFree (c->d_state);
   if (c->d_lctr) (void) hipFree (c->d_lctr);
-  if (c->d_fin) (void) hipFree (c->d_fin);
-  if (c->d_cursors) (void) hipFree (c->d_cursors);
-  if (c->h_ctr) (void) hipHostFree (c->h_ctr);
-  if (c->h_fin) (void) hipHostFree (c->h_fin);
-  if (c->h_cursors) (void) hipHostFree (c->h_cursors);
+  if (c->h_state) (void) hipHostFree (c->h_state);
   if (c->ev_s0) (void) hipEventDestroy (c->ev_s0);
   if (c->ev_s1) (void) hipEventDestroy (c->ev_s1);
   if (c->ev_f0) (void) hipEventDestroy (c->ev_f0);
@@ -2177,11 +2183,12 @@ static int clear_buckets (tjamd_counter *c)
 {
   if (!c->buckets_clean) {
     hipLaunchKernelGGL (clear_buckets_kernel, dim3 (TJ_P), dim3 (256), 0, c->stream, c->d_cursors, &c->d_ctr->n_null,
-                        (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj, c->ch_shift);
+                        (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj, c->ch_shift, c->d_fin, (u32 *) c->bins.p, c->bins.p ? BS_MAXBINS : 0);
     HIPCHK (hipGetLastError ());
     c->buckets_clean = true;
+    c->bins_zeroed = c->bins.p != nullptr;
   }
-  c->n_raw_known = 0; c->bucket_bound = 0; c->chunk_bound = TJ_P; c->ch_shift = -1;
+  c->n_raw_known = 0; c->raw_bound = 0; c->bucket_bound = 0; c->chunk_bound = TJ_P; c->ch_shift = -1;
   return TJAMD_OK;
 }
 
@@ -2215,11 +2222,15 @@ extern "C" int tjamd_sync (tjamd_counter *c)
 }
 
 // stream synchronisation + exact counts
-static int sync_counters (tjamd_counter *c)
+static int queue_counter_copies (tjamd_counter *c)
 {
-  HIPCHK (hipMemcpyAsync (c->h_ctr, c->d_ctr, sizeof (DevCounters), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK (hipMemcpyAsync (c->h_cursors, c->d_cursors, (TJ_P + 1) * sizeof (u32), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK (hipStreamSynchronize (c->stream));
+  HIPCHK (hipMemcpyAsync (c->h_state, c->d_state, sizeof (DevState), hipMemcpyDeviceToHost, c->stream));
+  return TJAMD_OK;
+}
+
+// the copies queued by queue_counter_copies() have arrived: errors, exact counts
+static int apply_counter_copies (tjamd_counter *c)
+{
   long total = 0;
   u64 mx = 0;
   for (int b = 0; b < TJ_P; b++) { total += c->h_cursors[b]; mx = std::max<u64> (mx, c->h_cursors[b]); }
@@ -2229,10 +2240,19 @@ static int sync_counters (tjamd_counter *c)
   if (c->h_ctr->fix_overflow) return set_err (TJAMD_ERR_CAPACITY, "too many non-ACGTU tract candidates in one batch (%llu)",
                                              (unsigned long long) std::max (c->h_ctr->lc[0].n_fix, c->h_ctr->lc[1].n_fix));
   c->n_raw_known = total - (long) c->h_ctr->n_null;
+  c->raw_bound = (u64) c->n_raw_known;
   c->bucket_bound = mx;
   c->chunk_bound = c->h_cursors[TJ_P];
   c->n_undefined = (long) c->h_ctr->n_undefined;
   return TJAMD_OK;
+}
+
+static int sync_counters (tjamd_counter *c)
+{
+  int rc = queue_counter_copies (c);
+  if (rc) return rc;
+  HIPCHK (hipStreamSynchronize (c->stream));
+  return apply_counter_copies (c);
 }
 
 // room for `add` more raw records (an upper bound), wherever the hash sends them, written by `grid` workgroups
@@ -2308,6 +2328,7 @@ extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t
   const long n_tiles = (long) ((n_bytes + TJ_SB_TILE - 1) / TJ_SB_TILE);
   const int grid = (int) std::min<long> (n_tiles, (long) c->n_cu * TJ_SB_WG_PER_CU);
   rc = ensure_buckets (c, bound, grid + 1);             // + the fix-up kernel's block-per-record inserts
+  c->raw_bound += (u64) (n_bytes / (size_t) mprime) + 1u;
   if (!rc) rc = ensure (c->fix, (size_t) TJ_FIX_CAP * sizeof (FixEntry), c->stream);
   if (rc) return rc;
   const uint8_t *seq = (const uint8_t *) d_stream;
@@ -2437,6 +2458,7 @@ extern "C" int tjamd_upload_raw (tjamd_counter *c, const hopo_element *elems, lo
   HIPCHK (hipSetDevice (c->device));
   int rc = sync_counters (c);
   if (!rc) rc = ensure_buckets (c, (u64) n, 0);
+  c->raw_bound += (u64) n;
   if (!rc) rc = ensure (c->stage, (size_t) n * 40, c->stream);
   if (rc) return rc;
   HIPCHK (hipMemcpyAsync (c->stage.p, elems, (size_t) n * 40, hipMemcpyHostToDevice, c->stream));
@@ -2578,7 +2600,7 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
   const int log2t = cov_table_bits (n1);
   const long t = 1l << log2t;
   int rc = ensure (c->alt, (size_t) n1 * 24, c->stream);
-  if (!rc) rc = ensure (c->bins, (size_t) (nbins + 1) * 4, c->stream);
+  if (!rc && !c->bins.p) { rc = ensure (c->bins, (size_t) (BS_MAXBINS + 1) * 4, c->stream); c->bins_zeroed = false; }
   if (!rc) rc = ensure (c->binstart, (size_t) (nbins + 1) * 4, c->stream);
   if (!rc) rc = ensure (c->binctx, (size_t) nbins * 8, c->stream);
   if (!rc) rc = ensure (c->headpos, (size_t) n1 * 4, c->stream);
@@ -2591,9 +2613,10 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
   u32 *tstart = (u32 *) c->headpos.p, *tend = (u32 *) c->outpos.p;
   u32 *ckeys = (u32 *) c->cov.p;
   int *csums = (int *) c->cov.p + t;
-  HIPCHK (hipMemsetAsync (bins, 0, (size_t) nbins * 4, c->stream));
-  HIPCHK (hipMemsetAsync (c->cov.p, 0, (size_t) t * 8, c->stream));
-  hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n1, c->k, nbits, bins);
+  if (!c->bins_zeroed) HIPCHK (hipMemsetAsync (bins, 0, (size_t) BS_MAXBINS * 4, c->stream));
+  c->bins_zeroed = false;
+  hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n1, c->k, nbits, bins,
+                      (uint4 *) c->cov.p, (long) (t / 2));
   hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, bins, nbins, binstart, c->bin_rank_max, c->d_fin);
   hipLaunchKernelGGL (bin_scatter_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins);
   hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 16384)), dim3 (64 * BSI_WAVES), 0, c->stream,
@@ -2614,31 +2637,48 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
 {
   if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
   HIPCHK (hipSetDevice (c->device));
-  int rc = sync_counters (c);
-  if (rc) return rc;
-  const long n = c->n_raw_known;
-  c->n_kept = 0; c->n_idx = 0; c->coverage = 0;
-  if (n == 0) { c->status = 1; if (status) *status = 1; return TJAMD_OK; }     // reference: src/hopo_counter.c:345-349
-  if (n >= (1l << 31)) return set_err (TJAMD_ERR_CAPACITY, "%ld raw records exceed the reference's int n_elem", n);
+  // The raw count sizes the kept list.  A survivor stands for at least two raw records (both strands seen, or a count
+  // above one), so half of the host's running upper bound of the raw count is a safe capacity: unless that is a lot of
+  // memory, the aggregation is launched without first asking the device (one host round trip less) and the exact
+  // counts and error flags, copied in stream order before the buckets are cleared, are looked at afterwards.
+  int rc = TJAMD_OK;
+  c->n_kept = 0; c->n_idx = 0; c->coverage = 0; c->fin_timed = false;
+  const bool speculative = (c->raw_bound / 2 + 1) * 24 <= (8ull << 30);
+  u64 kept_cap = c->raw_bound / 2 + 1;
+  if (!speculative) {
+    rc = sync_counters (c);
+    if (rc) return rc;
+    if (c->n_raw_known == 0) { c->status = 1; if (status) *status = 1; return TJAMD_OK; }     // reference: src/hopo_counter.c:345-349
+    if (c->n_raw_known >= (1l << 31)) return set_err (TJAMD_ERR_CAPACITY, "%ld raw records exceed the reference's int n_elem", c->n_raw_known);
+    kept_cap = (u64) c->n_raw_known / 2 + 1;
+  }
 
-  // steps 1-2: per-bucket hash aggregation + filter (reference :351-374).  Distinct keys <= raw records.
-  rc = ensure (c->kept, (size_t) n * 24, c->stream);
+  // steps 1-2: per-bucket hash aggregation + filter (reference :351-374)
+  rc = ensure (c->kept, (size_t) kept_cap * 24, c->stream);
   if (!rc && c->W <= 2) rc = ensure (c->ovf, c->pool.cap, c->stream);   // second pool for the aggregation's leftover rounds
   if (rc) return rc;
   HIPCHK (hipEventRecord (c->ev_f0, c->stream));
-  HIPCHK (hipMemsetAsync (c->d_fin, 0, sizeof (FinCounts), c->stream));
   const Buckets BK = make_buckets (c);
   switch (c->W) {
-    case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
-    case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
-    default: hipLaunchKernelGGL (aggregate_kernel<4>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, (u64) n, c->d_fin); break;
+    case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
+    case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
+    default: hipLaunchKernelGGL (aggregate_kernel<4>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
   }
   HIPCHK (hipGetLastError ());
-  // the aggregation consumed the buckets (leftover rounds reuse their fronts): the raw records are gone
-  rc = clear_buckets (c);
+  // counters, bucket sizes and the aggregation's own counts, in one copy; then the buckets are emptied (the aggregation
+  // consumed them: leftover rounds reuse their fronts) together with the counts the next aggregation adds to
+  rc = queue_counter_copies (c);
+  if (!rc) rc = clear_buckets (c);
   if (rc) return rc;
-  HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
   HIPCHK (hipStreamSynchronize (c->stream));
+  if (speculative) {
+    rc = apply_counter_copies (c);
+    const long n = c->n_raw_known;
+    c->n_raw_known = 0; c->raw_bound = 0; c->bucket_bound = 0; c->chunk_bound = TJ_P;      // (the buckets are empty again)
+    if (rc) return rc;
+    if (n == 0) { c->status = 1; if (status) *status = 1; return TJAMD_OK; }                // reference: src/hopo_counter.c:345-349
+    if (n >= (1l << 31)) return set_err (TJAMD_ERR_CAPACITY, "%ld raw records exceed the reference's int n_elem", n);
+  }
   if (c->h_fin->overflow) return set_err (TJAMD_ERR_CAPACITY, "kept list overflow");
   const long n1 = c->h_fin->n_kept;
   if (n1 == 0) {                                                               // reference :376-381
