@@ -5,8 +5,9 @@ A "step" is one pass of the hot path over one sample's reads: scan kernel (tract
 by the device finalise (sort / reduce / filter / index / coverage), with the read stream already resident in HBM.
 Workload at N=1: BASELINE.json configs[1] -- 1 sample, 10 M synthetic 150 bp single-end reads from a 5 Mb genome,
 k=10, min_tract=3, strand-bias filter on, min_coverage=5.  With N>1 GPUs every rank holds its own sample of that size
-(weak scaling, samples are independent: reference src/genome_set.c:66-94) and the step ends with the exchange the
-path has: an all-gather (RCCL) of the per-sample histograms.
+(weak scaling, samples are independent: reference src/genome_set.c:66-94) and the step includes the exchange the
+path has: an all-gatherv (RCCL) of the per-sample histograms and their merge, run on a second stream under the next
+sample's scan (the last one inside the timed region).
 
 Prints ONE JSON line on rank 0.  The CPU oracle is used only for the cpu_baseline leg (never in the timed GPU path).
 """
@@ -73,23 +74,49 @@ def main():
     n_bytes = host.size
     dev = torch.from_numpy(host).cuda()                 # resident in HBM before the timed region
     stream = torch.cuda.current_stream()
-    c = tj.Counter(k, device=local)
-    c.set_stream(stream.cuda_stream)
+    # N > 1: two counters take turns, so that a sample's histogram stays in place while the next sample is scanned; its
+    # exchange (all-gatherv + merge, on a stream and a counter of their own) runs under that scan.
+    ctrs = [tj.Counter(k, device=local) for _ in range(2 if world > 1 else 1)]
+    for cc in ctrs:
+        cc.set_stream(stream.cuda_stream)
+    c = ctrs[0]
+    side = merger = None
+    if world > 1:
+        side = torch.cuda.Stream()
+        merger = tj.Counter(k, device=local)
+        merger.set_stream(side.cuda_stream)
 
     gathered = None
+    pending = None                                        # counter whose histogram has not been exchanged yet
+    n_step = 0
+
+    def exchange(cnt):
+        nonlocal gathered
+        from tatajuba_amd.dist import all_gather_histograms, merge_histograms_device
+        with torch.cuda.stream(side):
+            rec, cnts = all_gather_histograms(cnt, dist)    # RCCL all-gatherv of the per-sample histograms
+            gathered = merge_histograms_device(merger, rec, cnts)   # every rank holds the union (reference: genome_set.c:250-289)
 
     def step():
-        nonlocal gathered
+        nonlocal pending, n_step, c
+        c = ctrs[n_step % len(ctrs)]
+        n_step += 1
         c.reset()
-        c.scan_device(dev.data_ptr(), n_bytes, m)
+        c.scan_device(dev.data_ptr(), n_bytes, m)       # asynchronous: the previous sample's exchange runs under it
+        if pending is not None:
+            exchange(pending)
         st = c.finalise(1, args.min_coverage)
         if st != 0:
             raise SystemExit(f"finalise status {st}")
-        if world > 1:                                     # exchange step: all-gatherv of the per-sample histograms
-            from tatajuba_amd.dist import all_gather_histograms, merge_histograms_device
-            rec, cnts = all_gather_histograms(c, dist)
-            gathered = merge_histograms_device(c, rec, cnts)    # every rank holds the merged union (reference: genome_set.c:250-289)
+        if world > 1:
+            pending = c
         return c.last_scan_ms(), c.last_finalise_ms()
+
+    def drain():                                          # the last sample's exchange
+        nonlocal pending
+        if pending is not None:
+            exchange(pending)
+            pending = None
 
     def fence():
         torch.cuda.synchronize()
@@ -103,12 +130,14 @@ def main():
     raw = c.raw_count()
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     t0 = time.perf_counter()
     scan_ms, fin_ms = [], []
     for _ in range(args.steps):
         a, b = step()
         scan_ms.append(a); fin_ms.append(b)
+    drain()
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -158,7 +187,7 @@ def main():
         "config": {"workload": f"{world} sample(s) x {args.reads} synthetic {L} bp single-end reads, genome {args.genome} bp, "
                                f"k={k} min_tract={m} remove_biased=1 min_coverage={args.min_coverage} (BASELINE.json configs[1] per GPU)",
                    "reads_per_gpu": args.reads, "raw_records_per_gpu": int(raw), "kept_records": int(kept),
-                   "parallelism": f"sample-per-gpu x{world}"},
+                   "parallelism": f"sample-per-gpu x{world}" + (", histogram exchange (all-gatherv + merge) overlapped with the next sample's scan" if world > 1 else "")},
         "roofline": roof,
         "stages": {"scan": {"ms": scan_avg, "algorithmic_GBps": scan_gbs, "frac_of_hbm_peak": scan_gbs / HBM_PEAK_GBS,
                             "reads_per_s": args.reads / (scan_avg * 1e-3)},
@@ -182,7 +211,10 @@ def main():
                                "host_cores_available": os.cpu_count()}
     if rank == 0:
         print(json.dumps(out))
-    c.close()
+    for cc in ctrs:
+        cc.close()
+    if merger is not None:
+        merger.close()
     if dist is not None:
         dist.destroy_process_group()
 

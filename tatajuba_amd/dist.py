@@ -27,15 +27,15 @@ def all_gatherv_bytes(local, dist, group=None):
         parts, sizes = all_gatherv_bytes(local.cpu(), dist, group)
         return [p.to(local.device) for p in parts], sizes
     n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    sizes_t = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes_t, n, group=group)
+    sizes = [int(x) for x in sizes_t.tolist()]              # the one host synchronisation of the exchange
     mx = max(max(sizes), 1)
     pad = torch.zeros(mx, dtype=torch.uint8, device=local.device)
     pad[: local.numel()] = local
-    out = [torch.empty(mx, dtype=torch.uint8, device=local.device) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return [o[:s] for o, s in zip(out, sizes)], sizes
+    out = torch.empty(world * mx, dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return [out[r * mx: r * mx + sz] for r, sz in enumerate(sizes)], sizes
 
 
 def all_gather_histograms(counter, dist, group=None):
