@@ -93,18 +93,45 @@ def main():
     def exchange(cnt):
         nonlocal gathered
         from tatajuba_amd.dist import all_gather_histograms, merge_histograms_device
+        torch.cuda.set_device(local)                      # (device and stream are per thread)
         with torch.cuda.stream(side):
             rec, cnts = all_gather_histograms(cnt, dist)    # RCCL all-gatherv of the per-sample histograms
             gathered = merge_histograms_device(merger, rec, cnts)   # every rank holds the union (reference: genome_set.c:250-289)
+
+    # The exchange has host synchronisations of its own (sizes, union size): it runs in a helper thread so that the main
+    # thread can go on to the finalise of the sample being scanned.  Only that thread issues collectives while the loop
+    # runs, one exchange at a time, in the same order on every rank.
+    import threading
+    worker = None
+    worker_err = []
+
+    def exchange_async(cnt):
+        nonlocal worker
+        def run():
+            try:
+                exchange(cnt)
+            except BaseException as e:                    # noqa: BLE001
+                worker_err.append(e)
+        worker = threading.Thread(target=run)
+        worker.start()
+
+    def exchange_join():
+        nonlocal worker
+        if worker is not None:
+            worker.join()
+            worker = None
+        if worker_err:
+            raise worker_err[0]
 
     def step():
         nonlocal pending, n_step, c
         c = ctrs[n_step % len(ctrs)]
         n_step += 1
+        exchange_join()                                   # (the exchange before last: long done)
         c.reset()
         c.scan_device(dev.data_ptr(), n_bytes, m)       # asynchronous: the previous sample's exchange runs under it
         if pending is not None:
-            exchange(pending)
+            exchange_async(pending)
         st = c.finalise(1, args.min_coverage)
         if st != 0:
             raise SystemExit(f"finalise status {st}")
@@ -114,6 +141,7 @@ def main():
 
     def drain():                                          # the last sample's exchange
         nonlocal pending
+        exchange_join()
         if pending is not None:
             exchange(pending)
             pending = None
