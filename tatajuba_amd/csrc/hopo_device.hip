@@ -1664,7 +1664,7 @@ void radix_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, lo
 // one partition by the leading bits of the key into ~n/32 bins, then every bin is rank-sorted in LDS by one wavefront.
 // Keys compare as the reference's qsort does (src/hopo_counter.c:28-38): base, ctx0, ctx1, signed length, descending.
 
-#define BS_MAXBITS   14
+#define BS_MAXBITS   16
 #define BS_RANK_MAX  256                // records of one bin a wavefront sorts in LDS; a fuller bin -> radix sort instead
 
 __device__ __forceinline__ u32 bin_of_record (u64 c0, u64 c1, u64 meta, int k, int nbits)
@@ -1687,43 +1687,66 @@ __device__ __forceinline__ bool record_before (u64 a0, u64 a1, u64 am, u32 ai, u
   return ai < bi;
 }
 
+// Sorted inputs (the merge: every sample's histogram is in key order) put a wavefront's 64 consecutive records into one or
+// two bins, and same-address atomics serialise: with `spread` the threads walk SPREAD_SEG interleaved segments instead,
+// neighbouring lanes far apart in the input.
+#define SPREAD_SEG 4096
+__device__ __forceinline__ long spread_span (long n, int spread) { return spread ? (long) SPREAD_SEG * ((n + SPREAD_SEG - 1) / SPREAD_SEG) : n; }
+__device__ __forceinline__ long spread_index (long g, long n, int spread)
+{ // a bijection of [0, spread_span) that covers [0, n): callers skip the indices >= n
+  if (!spread) return g;
+  const long seg_len = (n + SPREAD_SEG - 1) / SPREAD_SEG;
+  return (g % SPREAD_SEG) * seg_len + g / SPREAD_SEG;
+}
+
 __global__ __launch_bounds__ (256)
-void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32 *__restrict__ bins, uint4 *__restrict__ cov, long cov_vec)
+void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32 *__restrict__ bins, uint4 *__restrict__ cov, long cov_vec, int spread)
 { // (also empties the coverage table, which the sort pass three launches later fills: 16 bytes per store)
   for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < cov_vec; i += (long) gridDim.x * 256) cov[i] = make_uint4 (0, 0, 0, 0);
-  for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < n; i += (long) gridDim.x * 256) {
+  for (long g = (long) blockIdx.x * 256 + threadIdx.x; g < spread_span (n, spread); g += (long) gridDim.x * 256) {
+    const long i = spread_index (g, n, spread);
+    if (i >= n) continue;
     const u64 *p = in + 3 * i;
     atomicAdd (&bins[bin_of_record (p[0], p[1], p[2], k, nbits)], 1u);
   }
 }
 
-// Exclusive prefix of n <= BS_MAXBINS values by one workgroup of 1024 threads: coalesced load into LDS, every thread
-// sums a contiguous slice, one scan over the slice sums, coalesced store.  Returns the total; vmax = largest value.
+// Exclusive prefix of n values by one workgroup of 1024 threads, WGS_CHUNK at a time with a running carry: coalesced
+// load into LDS, every thread sums a contiguous slice, one scan over the slice sums, coalesced store.  Returns the
+// total; vmax = largest value.
 #define BS_MAXBINS (1 << BS_MAXBITS)
+#define WGS_CHUNK  16384
 
-struct WgScanLds { u32 a[BS_MAXBINS]; u32 wsum[16]; u32 vmax; };
+#define WGS_PAD(i) ((i) + ((i) >> 5))      // one pad word per 32: a thread's contiguous slice does not collide with its neighbours' banks
+struct WgScanLds { u32 a[WGS_CHUNK + WGS_CHUNK / 32 + 1]; u32 wsum[16]; u32 vmax; };
 
-__device__ __forceinline__ u32 wg_exclusive_scan (const u32 *__restrict__ in, int n, u32 *__restrict__ out, u32 *__restrict__ out2, WgScanLds &L, u32 &vmax)
+__device__ __forceinline__ u32 wg_exclusive_scan (const u32 *__restrict__ in, int n_all, u32 *__restrict__ out, u32 *__restrict__ out2, WgScanLds &L, u32 &vmax)
 {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (n + 1023) / 1024;
   if (tid == 0) L.vmax = 0;
-  for (int i = tid; i < n; i += 1024) L.a[i] = in[i];
-  __syncthreads ();
-  u32 sum = 0, mx = 0;
-  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < n) { const u32 v = L.a[b]; sum += v; mx = max (mx, v); } }
-  const u32 incl = wave_inclusive_scan (sum);
-  if (lane == 63) L.wsum[wave] = incl;
-  for (int o = 32; o > 0; o >>= 1) mx = max (mx, (u32) __shfl_down ((int) mx, o));
-  if (lane == 0 && mx) atomicMax (&L.vmax, mx);
-  __syncthreads ();
-  u32 run = incl - sum, total = 0;
-  for (int w = 0; w < 16; w++) { const u32 x = L.wsum[w]; if (w < wave) run += x; total += x; }
-  for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < n) { const u32 v = L.a[b]; L.a[b] = run; run += v; } }
-  __syncthreads ();
-  for (int i = tid; i < n; i += 1024) { const u32 v = L.a[i]; out[i] = v; if (out2) out2[i] = v; }
+  u32 carry = 0;
+  for (int base = 0; base < n_all; base += WGS_CHUNK) {
+    const int n = min (WGS_CHUNK, n_all - base);
+    const int per = (n + 1023) / 1024;
+    for (int i = tid; i < n; i += 1024) L.a[WGS_PAD (i)] = in[base + i];
+    __syncthreads ();
+    u32 sum = 0, mx = 0;
+    for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < n) { const u32 v = L.a[WGS_PAD (b)]; sum += v; mx = max (mx, v); } }
+    const u32 incl = wave_inclusive_scan (sum);
+    if (lane == 63) L.wsum[wave] = incl;
+    for (int o = 32; o > 0; o >>= 1) mx = max (mx, (u32) __shfl_down ((int) mx, o));
+    if (lane == 0 && mx) atomicMax (&L.vmax, mx);
+    __syncthreads ();
+    u32 run = carry + incl - sum, total = 0;
+    for (int w = 0; w < 16; w++) { const u32 x = L.wsum[w]; if (w < wave) run += x; total += x; }
+    for (int j = 0; j < per; j++) { const int b = tid * per + j; if (b < n) { const u32 v = L.a[WGS_PAD (b)]; L.a[WGS_PAD (b)] = run; run += v; } }
+    __syncthreads ();
+    for (int i = tid; i < n; i += 1024) { const u32 v = L.a[WGS_PAD (i)]; out[base + i] = v; if (out2) out2[base + i] = v; }
+    carry += total;
+    __syncthreads ();
+  }
   vmax = L.vmax;
-  return total;
+  return carry;
 }
 
 // bin counts -> binstart[0..nbins] and the scatter cursors (bins[] itself); a bin above rank_max switches the whole
@@ -2005,10 +2028,132 @@ void bin_ctx_write_kernel (const u32 *__restrict__ binstart, const u32 *__restri
   cov_max_part (cov_keys, cov_sums, t, &fin->coverage, s_best);
 }
 
+// ---- cross-sample merge on the bins --------------------------------------------------------------------------------
+// The samples' histograms, back to back, are partitioned by the same leading key bits; one wavefront per bin then finds
+// the distinct keys of its bin (the lowest-numbered record of each key represents it), their order, and the depth of
+// each key over all samples.  MG_RANK_MAX bounds a bin (a fuller one -> radix path).
+#define MG_RANK_MAX 256
+#define TJ_META_SAMPLE_SHIFT 52          // bits 52..63 of the bitfield word are unused by hopo_element
+
+__global__ __launch_bounds__ (256)
+void merge_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, long n, int k, int nbits, u32 *__restrict__ cursors,
+                           const long *__restrict__ starts, int n_samples)
+{ // bin_scatter_kernel + the sample index of every record written into the spare bits of its meta word
+  for (long g = (long) blockIdx.x * 256 + threadIdx.x; g < spread_span (n, 1); g += (long) gridDim.x * 256) {
+    const long i = spread_index (g, n, 1);
+    if (i >= n) continue;
+    int lo = 0, hi = n_samples;                         // starts[s] <= i < starts[s + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= i) lo = mid; else hi = mid; }
+    const u64 *p = in + 3 * i;
+    const u64 a = p[0], b = p[1], m = p[2];
+    u64 *q = out + 3 * (u64) atomicAdd (&cursors[bin_of_record (a, b, m, k, nbits)], 1u);
+    q[0] = a; q[1] = b; q[2] = (m & ((1ull << TJ_META_SAMPLE_SHIFT) - 1ull)) | ((u64) lo << TJ_META_SAMPLE_SHIFT);
+  }
+}
+
+__device__ __forceinline__ bool merge_same_key (u64 a0, u64 a1, u64 am, u64 b0, u64 b1, u64 bm)
+{
+  const u64 km = (3ull << TJ_META_BASE_SHIFT) | (0x3FFull << TJ_META_LEN_SHIFT);
+  return a0 == b0 && a1 == b1 && ((am ^ bm) & km) == 0ull;
+}
+
+// per bin: binctx[bin] = distinct keys; per record (at its place st + t in the partitioned array): tpos = rank of its
+// key among the bin's distinct keys, ttot = depth of the key over all samples if the record represents its key, else ~0.
+// Inside a bin the base is the same (it is the bin's leading bit), so keys compare as (ctx0, ctx1, length ^ 0x200).
+__global__ __launch_bounds__ (64)
+void bin_merge_kernel (const u64 *__restrict__ rec, const u32 *__restrict__ binstart, int nbins, const FinCounts *fin,
+                       u32 *__restrict__ binctx, u32 *__restrict__ tpos, u32 *__restrict__ ttot)
+{
+  __shared__ u64 R[3 * MG_RANK_MAX];
+  __shared__ u32 H[MG_RANK_MAX];                        // records in front of this one's key | representative << 31
+  if (fin->sort_fallback) return;
+  const int lane = threadIdx.x;
+  for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
+    const u32 st = binstart[bin], s = binstart[bin + 1] - st;
+    if (s == 0) { if (lane == 0) binctx[bin] = 0; continue; }
+    for (u32 w = lane; w < 3 * s; w += 64) {
+      u64 v = rec[3 * (u64) st + w];
+      if (w % 3 == 2) v = (v & ~(0x3FFull << TJ_META_LEN_SHIFT)) | ((((v >> TJ_META_LEN_SHIFT) & 0x3FFull) ^ 0x200ull) << TJ_META_LEN_SHIFT);   // length as an unsigned sort key
+      R[w] = v;
+    }
+    asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier ();
+    const u64 lmask = 0x3FFull << TJ_META_LEN_SHIFT;
+    u32 nrep = 0;
+    for (u32 t0 = 0; t0 < s; t0 += 64) {                // pass 1: records in front, who represents its key, the key's depth
+      const u32 t = t0 + lane;
+      bool rep = false;
+      if (t < s) {
+        const u64 a0 = R[3 * t], a1 = R[3 * t + 1], al = R[3 * t + 2] & lmask;
+        rep = true;
+        u32 tot = 0, r = 0;
+        for (u32 j = 0; j < s; j++) {
+          const u64 b0 = R[3 * j], b1 = R[3 * j + 1], bm = R[3 * j + 2], bl = bm & lmask;
+          const bool same = (b0 == a0) & (b1 == a1) & (bl == al);
+          const bool before = (b0 > a0) | ((b0 == a0) & ((b1 > a1) | ((b1 == a1) & (bl > al))));
+          r += before ? 1u : 0u;
+          if (same) { if (j < t) rep = false; tot += (u32) meta_count (bm); }
+        }
+        H[t] = r | (rep ? 0x80000000u : 0u);
+        ttot[st + t] = rep ? tot : 0xFFFFFFFFu;
+      }
+      nrep += (u32) __popcll (__ballot (rep));
+    }
+    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier ();
+    for (u32 t = lane; t < s; t += 64) {                // pass 2: distinct keys in front = representatives with fewer records in front
+      const u32 r = H[t] & 0x7FFFFFFFu;
+      u32 d = 0;
+      for (u32 j = 0; j < s; j++) { const u32 h = H[j]; d += ((h & 0x80000000u) && (h & 0x7FFFFFFFu) < r) ? 1u : 0u; }
+      tpos[st + t] = d;
+    }
+    if (lane == 0) binctx[bin] = nrep;
+    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier ();
+  }
+}
+
+// union keys in order with the total depth in the count field, and the per-sample depth matrix
+__global__ __launch_bounds__ (256)
+void bin_merge_write_kernel (const u64 *__restrict__ rec, const u32 *__restrict__ binstart, const u32 *__restrict__ binout, int nbins, const FinCounts *fin,
+                             const u32 *__restrict__ tpos, const u32 *__restrict__ ttot, int n_samples,
+                             u64 *__restrict__ keys, int *__restrict__ counts, long cap)
+{
+  if (fin->sort_fallback) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int bin = blockIdx.x * 4 + wave; bin < nbins; bin += gridDim.x * 4) {
+    const u32 st = binstart[bin], s = binstart[bin + 1] - st, o0 = binout[bin];
+    for (u32 t0 = 0; t0 < s; t0 += 64) {                // representatives come first in a bin's index order: rows are
+      const u32 t = t0 + lane;                          // zeroed (same wave, program order) before anybody fills them
+      if (t < s) {
+        const long u = (long) o0 + tpos[st + t];
+        if (u < cap) {
+          const u64 a0 = rec[3 * (u64) (st + t)], a1 = rec[3 * (u64) (st + t) + 1], am = rec[3 * (u64) (st + t) + 2];
+          const u32 tot = ttot[st + t];
+          if (tot != 0xFFFFFFFFu) {
+            for (int q = 0; q < n_samples; q++) counts[u * n_samples + q] = 0;
+            u64 m = am & ((1ull << TJ_META_SAMPLE_SHIFT) - 1ull);
+            m = (m & ~(0xFFFFFull << TJ_META_COUNT_SHIFT)) | (((u64) tot & 0xFFFFFull) << TJ_META_COUNT_SHIFT);
+            keys[3 * u] = a0; keys[3 * u + 1] = a1; keys[3 * u + 2] = m;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier ();
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+      if (t < s) {
+        const long u = (long) o0 + tpos[st + t];
+        if (u < cap) {
+          const u64 am = rec[3 * (u64) (st + t) + 2];
+          counts[u * n_samples + (int) (am >> TJ_META_SAMPLE_SHIFT)] = meta_count (am);
+        }
+      }
+    }
+  }
+}
+
 __global__ void set_int_kernel (int *p, int v) { *p = v; }
 
-// ---- cross-sample merge (context-keyed union of the samples' histograms; reference precursor: src/genome_set.c:250-289)
-#define TJ_META_SAMPLE_SHIFT 52          // bits 52..63 of the bitfield word are unused by hopo_element
+// ---- cross-sample merge, radix path (context-keyed union of the samples' histograms; reference precursor: src/genome_set.c:250-289)
 
 __global__ void merge_tag_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, long n, const long *__restrict__ starts, int n_samples)
 { // copy + write the sample index of every record into the spare bits of its meta word
@@ -2616,7 +2761,7 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
   if (!c->bins_zeroed) HIPCHK (hipMemsetAsync (bins, 0, (size_t) BS_MAXBINS * 4, c->stream));
   c->bins_zeroed = false;
   hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n1, c->k, nbits, bins,
-                      (uint4 *) c->cov.p, (long) (t / 2));
+                      (uint4 *) c->cov.p, (long) (t / 2), 0);
   hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, bins, nbins, binstart, c->bin_rank_max, c->d_fin);
   hipLaunchKernelGGL (bin_scatter_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins);
   hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 16384)), dim3 (64 * BSI_WAVES), 0, c->stream,
@@ -2755,6 +2900,9 @@ extern "C" double tjamd_last_finalise_ms (tjamd_counter *c)
 
 extern "C" long tjamd_last_scan_launches (tjamd_counter *c) { return c ? c->last_scan_launches : -1; }
 
+// radix path of the merge: tag, stable sort, run heads, scans (any size, any skew)
+static long merge_samples_radix (tjamd_counter *c, const void *d_records, long n, int n_samples, void *d_out_keys, void *d_out_counts, long capacity);
+
 extern "C" long tjamd_merge_samples (tjamd_counter *c, const void *d_records, const long *counts, int n_samples,
                                       void *d_out_keys, void *d_out_counts, long capacity)
 {
@@ -2766,16 +2914,56 @@ extern "C" long tjamd_merge_samples (tjamd_counter *c, const void *d_records, co
   starts[n_samples] = n;
   if (n == 0) return 0;
   if (!d_records) return -set_err (TJAMD_ERR_ARG, "null records");
+  if (n >= (1l << 31)) return -set_err (TJAMD_ERR_CAPACITY, "%ld records to merge", n);
+
+  // bins of ~32..64 records: partition, then one wavefront per bin finds the distinct keys, their order and depths
+  int nbits = 6;
+  while (nbits < BS_MAXBITS && nbits < 1 + 4 * c->k && (64l << nbits) < n) nbits++;
+  nbits = std::min (nbits, 1 + 4 * c->k);
+  const int nbins = 1 << nbits;
   int rc = ensure (c->prefix, (size_t) (n_samples + 1) * 8, c->stream);
-  if (!rc) rc = ensure (c->rawlist, (size_t) n * 24, c->stream);
+  if (!rc) rc = ensure (c->alt, (size_t) n * 24, c->stream);
+  if (!rc && !c->bins.p) { rc = ensure (c->bins, (size_t) (BS_MAXBINS + 1) * 4, c->stream); c->bins_zeroed = false; }
+  if (!rc) rc = ensure (c->binstart, (size_t) (BS_MAXBINS + 1) * 4, c->stream);
+  if (!rc) rc = ensure (c->binctx, (size_t) BS_MAXBINS * 8, c->stream);
+  if (!rc) rc = ensure (c->headpos, (size_t) n * 4, c->stream);
+  if (!rc) rc = ensure (c->outpos, (size_t) n * 4, c->stream);
+  if (rc) return -rc;
+  if (hipMemcpyAsync (c->prefix.p, starts.data (), (size_t) (n_samples + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  u32 *bins = (u32 *) c->bins.p, *binstart = (u32 *) c->binstart.p, *binctx = (u32 *) c->binctx.p, *binout = binctx + nbins;
+  u32 *tpos = (u32 *) c->headpos.p, *ttot = (u32 *) c->outpos.p;
+  if (!c->bins_zeroed && hipMemsetAsync (bins, 0, (size_t) BS_MAXBINS * 4, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "memset failed");
+  c->bins_zeroed = false;
+  hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) d_records, n, c->k, nbits, bins, (uint4 *) nullptr, 0l, 1);
+  hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, bins, nbins, binstart,
+                      c->bin_rank_max < (u32) BS_RANK_MAX ? c->bin_rank_max : (u32) MG_RANK_MAX, c->d_fin);   // (test hook: see TATAJUBA_AMD_BIN_MAX)
+  hipLaunchKernelGGL (merge_scatter_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) d_records, (u64 *) c->alt.p, n, c->k, nbits, bins,
+                      (const long *) c->prefix.p, n_samples);
+  hipLaunchKernelGGL (bin_merge_kernel, dim3 ((unsigned) std::min (nbins, 16384)), dim3 (64), 0, c->stream, (const u64 *) c->alt.p, (const u32 *) binstart, nbins,
+                      (const FinCounts *) c->d_fin, binctx, tpos, ttot);
+  hipLaunchKernelGGL (bin_ctx_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, (const u32 *) binctx, nbins, binout, c->d_fin);
+  hipLaunchKernelGGL (bin_merge_write_kernel, dim3 ((unsigned) std::min (nbins / 4 + 1, 4096)), dim3 (256), 0, c->stream, (const u64 *) c->alt.p, (const u32 *) binstart,
+                      (const u32 *) binout, nbins, (const FinCounts *) c->d_fin, (const u32 *) tpos, (const u32 *) ttot, n_samples,
+                      (u64 *) d_out_keys, (int *) d_out_counts, capacity);
+  if (hipGetLastError () != hipSuccess) return -set_err (TJAMD_ERR_HIP, "merge launch failed");
+  if (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "merge failed: %s", hipGetErrorString (hipGetLastError ()));
+  if (c->h_fin->sort_fallback) return merge_samples_radix (c, d_records, n, n_samples, d_out_keys, d_out_counts, capacity);
+  const long n_union = c->h_fin->n_idx;
+  if (n_union > capacity) return -set_err (TJAMD_ERR_CAPACITY, "%ld union keys, caller capacity %ld", n_union, capacity);
+  return n_union;
+}
+
+static long merge_samples_radix (tjamd_counter *c, const void *d_records, long n, int n_samples, void *d_out_keys, void *d_out_counts, long capacity)
+{
+  int rc = ensure (c->rawlist, (size_t) n * 24, c->stream);
   if (!rc) rc = ensure (c->alt, (size_t) n * 24, c->stream);
   if (!rc) rc = ensure (c->flags, (size_t) n * 4, c->stream);
   if (!rc) rc = ensure (c->segid, (size_t) n * 4, c->stream);
   if (!rc) rc = ensure (c->keep, (size_t) n * 4, c->stream);          // totals per union key
   if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n) * 4, c->stream);
   if (rc) return -rc;
-  if (hipMemcpyAsync (c->prefix.p, starts.data (), (size_t) (n_samples + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
   hipLaunchKernelGGL (merge_tag_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) d_records, (u64 *) c->rawlist.p, n, (const long *) c->prefix.p, n_samples);
   u64 *a = (u64 *) c->rawlist.p, *b = (u64 *) c->alt.p;
   rc = radix_sort_records (c, a, b, n);               // the reference's order; the sample tag does not take part

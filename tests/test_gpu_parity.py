@@ -460,29 +460,38 @@ def test_many_small_batches_grow_the_bucket_storage(k, m):
     c.close()
 
 
-def test_merge_samples_device():
-    """cross-sample merge on the GPU == the numpy union (tatajuba_amd/dist.py), counts per sample and key order"""
+@pytest.mark.parametrize("k,n_samples,force_radix", [(15, 3, False), (15, 3, True), (10, 8, False), (25, 5, False), (32, 2, False), (2, 4, False)])
+def test_merge_samples_device(monkeypatch, k, n_samples, force_radix):
+    """cross-sample merge on the GPU == the numpy union (tatajuba_amd/dist.py), counts per sample and key order; the
+    bin path and (forced through the test hook) the radix path"""
     torch = pytest.importorskip("torch")
     from tatajuba_amd.dist import merge_histograms_device, merge_histograms_host, device_bytes_tensor
     parts, counts, counters = [], [], []
-    for smp in range(3):
+    for smp in range(n_samples):
         s = tj.synth_stream(30000, 150, 200000, seed_reads=0x7A7A1000 + smp, variant_seed=smp)
-        c = tj.Counter(15)
-        c.scan_host(s, 4)
+        c = tj.Counter(k)
+        c.scan_host(s, 4 if k > 2 else 1)
         assert c.finalise(1, 0) == 0
         counters.append(c)
         counts.append(c.n_kept)
         parts.append(device_bytes_tensor(c.kept_device_ptr, c.n_kept * 24, torch.device("cuda", 0)).clone())
     rec = torch.cat(parts)
-    keys_d, mat_d = merge_histograms_device(counters[0], rec, counts)
+    if force_radix:
+        monkeypatch.setenv("TATAJUBA_AMD_BIN_MAX", "1")
+    merger = tj.Counter(k)
+    keys_d, mat_d = merge_histograms_device(merger, rec, counts)
     keys_h, mat_h = merge_histograms_host(rec.cpu().numpy(), counts)
     kd = np.frombuffer(keys_d.cpu().numpy().tobytes(), dtype=tj.RECORD_DTYPE)
     dd = tj.decode_meta(kd["meta"])
-    assert len(kd) == len(keys_h)
+    assert len(kd) == len(keys_h) > 0
     assert (kd["ctx0"] == keys_h["ctx0"]).all() and (kd["ctx1"] == keys_h["ctx1"]).all()
     assert (dd["base"] == keys_h["base"]).all() and (dd["length"] == keys_h["length"]).all()
     assert (mat_d.cpu().numpy() == mat_h).all()
     assert (dd["count"] == mat_h.sum(axis=1)).all()
+    # twice through the same merger (its buffers and counters are reused)
+    keys_2, mat_2 = merge_histograms_device(merger, rec, counts)
+    assert torch.equal(keys_2, keys_d) and torch.equal(mat_2, mat_d)
+    merger.close()
     for c in counters:
         c.close()
 
