@@ -1688,26 +1688,37 @@ __device__ __forceinline__ bool record_before (u64 a0, u64 a1, u64 am, u32 ai, u
 }
 
 // Sorted inputs (the merge: every sample's histogram is in key order) put a wavefront's 64 consecutive records into one or
-// two bins, and same-address atomics serialise: with `spread` the threads walk SPREAD_SEG interleaved segments instead,
-// neighbouring lanes far apart in the input.
-#define SPREAD_SEG 4096
-__device__ __forceinline__ long spread_span (long n, int spread) { return spread ? (long) SPREAD_SEG * ((n + SPREAD_SEG - 1) / SPREAD_SEG) : n; }
-__device__ __forceinline__ long spread_index (long g, long n, int spread)
-{ // a bijection of [0, spread_span) that covers [0, n): callers skip the indices >= n
-  if (!spread) return g;
-  const long seg_len = (n + SPREAD_SEG - 1) / SPREAD_SEG;
-  return (g % SPREAD_SEG) * seg_len + g / SPREAD_SEG;
+// two bins, and the device's global-atomic rate (~24 G/s, whatever the addresses) is what these kernels run at: with
+// `grouped` the lanes of a wavefront that share a bin send ONE atomic (peeling one distinct bin per round).
+// Returns the lane's position in its bin (scatter) -- or nothing useful for a pure count.
+__device__ __forceinline__ u32 bin_reserve (u32 *__restrict__ cursors, u32 bin, bool active, int grouped)
+{
+  if (!grouped) return active ? atomicAdd (&cursors[bin], 1u) : 0u;
+  const int lane = threadIdx.x & 63;
+  u64 todo = __ballot (active);
+  u32 pos = 0;
+  while (todo) {
+    const int leader = __ffsll ((long long) todo) - 1;
+    const u32 lb = (u32) __builtin_amdgcn_readlane ((int) bin, leader);
+    const u64 grp = __ballot (active && bin == lb) & todo;
+    u32 base = 0;
+    if (lane == leader) base = atomicAdd (&cursors[lb], (u32) __popcll (grp));
+    base = (u32) __builtin_amdgcn_readlane ((int) base, leader);
+    if ((grp >> lane) & 1ull) pos = base + (u32) __popcll (grp & ((1ull << lane) - 1ull));
+    todo &= ~grp;
+  }
+  return pos;
 }
 
 __global__ __launch_bounds__ (256)
-void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32 *__restrict__ bins, uint4 *__restrict__ cov, long cov_vec, int spread)
+void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32 *__restrict__ bins, uint4 *__restrict__ cov, long cov_vec, int grouped)
 { // (also empties the coverage table, which the sort pass three launches later fills: 16 bytes per store)
   for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < cov_vec; i += (long) gridDim.x * 256) cov[i] = make_uint4 (0, 0, 0, 0);
-  for (long g = (long) blockIdx.x * 256 + threadIdx.x; g < spread_span (n, spread); g += (long) gridDim.x * 256) {
-    const long i = spread_index (g, n, spread);
-    if (i >= n) continue;
-    const u64 *p = in + 3 * i;
-    atomicAdd (&bins[bin_of_record (p[0], p[1], p[2], k, nbits)], 1u);
+  for (long i0 = (long) blockIdx.x * 256; i0 < n; i0 += (long) gridDim.x * 256) {     // (wave-uniform trip count: ballots inside)
+    const long i = i0 + threadIdx.x;
+    u32 bin = 0;
+    if (i < n) { const u64 *p = in + 3 * i; bin = bin_of_record (p[0], p[1], p[2], k, nbits); }
+    (void) bin_reserve (bins, bin, i < n, grouped);
   }
 }
 
@@ -1957,7 +1968,11 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
   for (int bin = blockIdx.x * BSI_WAVES + wave; bin < nbins; bin += gridDim.x * BSI_WAVES) {
     const u32 st = binstart[bin], s = binstart[bin + 1] - st;
     if (s == 0) { if (lane == 0) binctx[bin] = 0; continue; }
-    for (u32 w = lane; w < 3 * s; w += 64) R[w] = in[3 * (u64) st + w];
+    for (u32 t = lane; t < s; t += 64) {                // one record per lane: its three loads are in flight together
+      const u64 *p = in + 3 * (u64) (st + t);
+      const u64 v0 = p[0], v1 = p[1], v2 = p[2];
+      R[3 * t] = v0; R[3 * t + 1] = v1; R[3 * t + 2] = v2;
+    }
     asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // wave-private LDS: in-order, only the data must have landed
     __builtin_amdgcn_wave_barrier ();
     u32 nkeep = 0;
@@ -2039,15 +2054,22 @@ __global__ __launch_bounds__ (256)
 void merge_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, long n, int k, int nbits, u32 *__restrict__ cursors,
                            const long *__restrict__ starts, int n_samples)
 { // bin_scatter_kernel + the sample index of every record written into the spare bits of its meta word
-  for (long g = (long) blockIdx.x * 256 + threadIdx.x; g < spread_span (n, 1); g += (long) gridDim.x * 256) {
-    const long i = spread_index (g, n, 1);
-    if (i >= n) continue;
-    int lo = 0, hi = n_samples;                         // starts[s] <= i < starts[s + 1]
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= i) lo = mid; else hi = mid; }
-    const u64 *p = in + 3 * i;
-    const u64 a = p[0], b = p[1], m = p[2];
-    u64 *q = out + 3 * (u64) atomicAdd (&cursors[bin_of_record (a, b, m, k, nbits)], 1u);
-    q[0] = a; q[1] = b; q[2] = (m & ((1ull << TJ_META_SAMPLE_SHIFT) - 1ull)) | ((u64) lo << TJ_META_SAMPLE_SHIFT);
+  for (long i0 = (long) blockIdx.x * 256; i0 < n; i0 += (long) gridDim.x * 256) {
+    const long i = i0 + threadIdx.x;
+    const bool active = i < n;
+    u64 a = 0, b = 0, m = 0;
+    int lo = 0;
+    if (active) {
+      int hi = n_samples;                               // starts[s] <= i < starts[s + 1]
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= i) lo = mid; else hi = mid; }
+      const u64 *p = in + 3 * i;
+      a = p[0]; b = p[1]; m = p[2];
+    }
+    const u32 pos = bin_reserve (cursors, active ? bin_of_record (a, b, m, k, nbits) : 0u, active, 1);
+    if (active) {
+      u64 *q = out + 3 * (u64) pos;
+      q[0] = a; q[1] = b; q[2] = (m & ((1ull << TJ_META_SAMPLE_SHIFT) - 1ull)) | ((u64) lo << TJ_META_SAMPLE_SHIFT);
+    }
   }
 }
 
@@ -2071,10 +2093,11 @@ void bin_merge_kernel (const u64 *__restrict__ rec, const u32 *__restrict__ bins
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
     const u32 st = binstart[bin], s = binstart[bin + 1] - st;
     if (s == 0) { if (lane == 0) binctx[bin] = 0; continue; }
-    for (u32 w = lane; w < 3 * s; w += 64) {
-      u64 v = rec[3 * (u64) st + w];
-      if (w % 3 == 2) v = (v & ~(0x3FFull << TJ_META_LEN_SHIFT)) | ((((v >> TJ_META_LEN_SHIFT) & 0x3FFull) ^ 0x200ull) << TJ_META_LEN_SHIFT);   // length as an unsigned sort key
-      R[w] = v;
+    for (u32 t = lane; t < s; t += 64) {                // one record per lane: its three loads are in flight together
+      const u64 *p = rec + 3 * (u64) (st + t);
+      const u64 v0 = p[0], v1 = p[1], v2 = p[2];
+      R[3 * t] = v0; R[3 * t + 1] = v1;
+      R[3 * t + 2] = (v2 & ~(0x3FFull << TJ_META_LEN_SHIFT)) | ((((v2 >> TJ_META_LEN_SHIFT) & 0x3FFull) ^ 0x200ull) << TJ_META_LEN_SHIFT);   // length as an unsigned sort key
     }
     asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier ();
