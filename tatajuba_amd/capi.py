@@ -79,7 +79,7 @@ EXPORTS = [
     "dna_in_2_bits", "bit_2_dna",
     "tjamd_device_count", "tjamd_last_error", "tjamd_version", "tjamd_counter_create", "tjamd_counter_destroy",
     "tjamd_counter_reset", "tjamd_counter_set_stream", "tjamd_counter_device", "tjamd_scan_device", "tjamd_scan_host",
-    "tjamd_scan_host_located", "tjamd_host_alloc", "tjamd_host_free", "tjamd_sync", "tjamd_raw_count",
+    "tjamd_scan_host_located", "tjamd_read_file_stream_mt", "tjamd_host_alloc", "tjamd_host_free", "tjamd_sync", "tjamd_raw_count",
     "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_kept_count",
     "tjamd_n_idx", "tjamd_coverage", "tjamd_download_kept", "tjamd_download_idx", "tjamd_kept_device_ptr",
     "tjamd_merge_samples", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches",
@@ -202,6 +202,21 @@ def synth_stream(n_reads, read_len, genome_len, seed_genome=0x7A7A0001, seed_rea
     if got != need:
         raise TatajubaAmdError("synthetic stream generation failed")
     return out[:need]
+
+
+def read_file_stream_mt(path, n_threads=4, window_bytes=0):
+    """read_file_stream through the multi-threaded feeder (plain files; host-only)."""
+    L = lib()
+    L.tjamd_read_file_stream_mt.restype = C.c_long
+    L.tjamd_read_file_stream_mt.argtypes = [C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_long), C.c_int, C.c_long]
+    n = C.c_long(0)
+    need = L.tjamd_read_file_stream_mt(os.fsencode(path), None, 0, C.byref(n), n_threads, window_bytes)
+    if need < 0:
+        raise FileNotFoundError(path)
+    out = np.empty(max(need, 1), dtype=np.uint8)
+    got = L.tjamd_read_file_stream_mt(os.fsencode(path), out.ctypes.data, need, C.byref(n), n_threads, window_bytes)
+    assert got == need
+    return out[:need], n.value
 
 
 def read_file_stream(path):

@@ -16,6 +16,9 @@ struct tjr_reader
   size_t pos, end;
   int drained;          /* the last gzread came back short: nothing more after this block */
   int marker_seen;      /* the '>' / '@' of the next record has already been consumed */
+  int in_memory;        /* blk is the caller's (whole input, nothing to refill or free) */
+  size_t marker_pos;    /* offset in blk of the marker of the next record (marker_seen) / of the record returned last */
+  size_t rec_start;
   tjr_text seq, qual;
 };
 
@@ -85,12 +88,26 @@ tjr_open (const char *path)
   return r;
 }
 
+tjr_reader *
+tjr_open_mem (const unsigned char *data, size_t n_bytes, size_t start)
+{
+  tjr_reader *r = (tjr_reader *) calloc (1, sizeof (tjr_reader));
+  r->blk = (unsigned char *) data;
+  r->pos = start < n_bytes ? start : n_bytes;
+  r->end = n_bytes;
+  r->drained = 1;
+  r->in_memory = 1;
+  return r;
+}
+
+size_t tjr_record_start (const tjr_reader *r) { return r->rec_start; }
+
 void
 tjr_close (tjr_reader *r)
 {
   if (!r) return;
-  gzclose (r->f);
-  free (r->blk); free (r->seq.s); free (r->qual.s); free (r);
+  if (!r->in_memory) { gzclose (r->f); free (r->blk); }
+  free (r->seq.s); free (r->qual.s); free (r);
 }
 
 long
@@ -101,7 +118,9 @@ tjr_next (tjr_reader *r, const char **seq)
   if (!r->marker_seen) {                       /* hunt for the next record marker, wherever it is */
     do c = tjr_byte (r); while (c != -1 && c != '>' && c != '@');
     if (c == -1) return -1;
+    r->marker_pos = r->pos - 1;
   }
+  r->rec_start = r->marker_pos;
   r->marker_seen = 0;
   r->seq.len = r->qual.len = 0;
   if (tjr_line (r, NULL) < 0) return -1;       /* header line: name and comment are not needed */
@@ -113,7 +132,7 @@ tjr_next (tjr_reader *r, const char **seq)
     tjr_push (&r->seq, &ch, 1);
     tjr_line (r, &r->seq);
   }
-  if (c == '>' || c == '@') r->marker_seen = 1;
+  if (c == '>' || c == '@') { r->marker_seen = 1; r->marker_pos = r->pos - 1; }
   if (!r->seq.s) tjr_push (&r->seq, (const unsigned char *) "", 0);
   *seq = r->seq.s;
   if (c != '+') return (long) r->seq.len;      /* FASTA record (or end of input) */

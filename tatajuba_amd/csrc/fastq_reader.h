@@ -13,4 +13,11 @@ tjr_reader *tjr_open (const char *path);                 /* NULL if the file can
 long tjr_next (tjr_reader *r, const char **seq);
 void tjr_close (tjr_reader *r);
 
+/* The same reader over bytes already in memory (a plain, uncompressed file that was mapped): no copies, positions are
+ * offsets into the block.  tjr_record_start() = offset of the '>' / '@' that opened the record tjr_next() returned last;
+ * a reader started exactly there (fresh state) returns that record and everything after it identically -- what the
+ * multi-threaded feeder's consistency check rests on. */
+tjr_reader *tjr_open_mem (const unsigned char *data, size_t n_bytes, size_t start);
+size_t tjr_record_start (const tjr_reader *r);
+
 #endif

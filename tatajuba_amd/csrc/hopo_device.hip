@@ -475,8 +475,8 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     STAMP (2);
     lds_barrier ();
     STAMP (3);
-#if defined(TJ_EXP_STOP_AFTER) && TJ_EXP_STOP_AFTER == 1
-    continue;
+#if defined(TJ_EXP_STOP_AFTER) && TJ_EXP_STOP_AFTER == 1       // experiment builds only (tools/exp_scan_pmc.sh)
+    { if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + TJ_TILE_GROUP; } tile = nt; it++; continue; }
 #endif
 
     // ---- phase 2: candidate tract starts among this lane's 16 positions ------------------------------------
@@ -500,7 +500,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     lds_barrier ();
     STAMP (5);
 #if defined(TJ_EXP_STOP_AFTER) && TJ_EXP_STOP_AFTER == 2
-    continue;
+    { if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + TJ_TILE_GROUP; } tile = nt; it++; continue; }
 #endif
 
     // ---- phase 3: one lane per candidate --------------------------------------------------------------------
@@ -2375,7 +2375,7 @@ extern "C" int tjamd_counter_reset (tjamd_counter *c)
 extern "C" void *tjamd_host_alloc (size_t bytes)
 {
   void *p = nullptr;
-  if (hipHostMalloc (&p, bytes, hipHostMallocDefault) != hipSuccess) { set_err (TJAMD_ERR_HIP, "hipHostMalloc of %zu bytes failed", bytes); return NULL; }
+  if (hipHostMalloc (&p, bytes, hipHostMallocPortable) != hipSuccess) { set_err (TJAMD_ERR_HIP, "hipHostMalloc of %zu bytes failed", bytes); return NULL; }   // (portable: batch buffers are pooled across the counters of all devices)
   return p;
 }
 

@@ -6,7 +6,11 @@
  * needs results prints an error and exits, like the reference's biomcmc_error().
  */
 #include "../../include/tatajuba_amd.h"
+#include <pthread.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "fastq_reader.h"
+#include "feeder.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -103,6 +107,83 @@ del_hopo_counter (hopo_counter hc)
   free (hc);
 }
 
+/* ---- multi-threaded feeder for plain files (feeder.c): its sink is the device scan ---------------------------------- */
+
+typedef struct { tjamd_counter *dev; int min_tract_size; } tj_gpu_sink;
+
+/* Pinned batch buffers are kept for the next file: pinning and unpinning half a gigabyte costs as much as parsing it.
+ * A small process-wide pool (the caller's sample threads share it); at most TJ_PIN_POOL_BYTES stay cached. */
+#define TJ_PIN_POOL_SLOTS 128
+#define TJ_PIN_POOL_BYTES (2l << 30)
+static struct { void *p; size_t bytes; int in_use; } tj_pin_pool[TJ_PIN_POOL_SLOTS];
+static pthread_mutex_t tj_pin_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void *
+tj_pinned_get (size_t bytes)
+{
+  int i;
+  void *p = NULL;
+  pthread_mutex_lock (&tj_pin_lock);
+  for (i = 0; i < TJ_PIN_POOL_SLOTS; i++)
+    if (tj_pin_pool[i].p && !tj_pin_pool[i].in_use && tj_pin_pool[i].bytes >= bytes && tj_pin_pool[i].bytes <= 2 * bytes) {
+      tj_pin_pool[i].in_use = 1; p = tj_pin_pool[i].p; break;
+    }
+  pthread_mutex_unlock (&tj_pin_lock);
+  if (p) return p;
+  p = tjamd_host_alloc (bytes);
+  if (!p) return NULL;
+  pthread_mutex_lock (&tj_pin_lock);
+  for (i = 0; i < TJ_PIN_POOL_SLOTS; i++) if (!tj_pin_pool[i].p) { tj_pin_pool[i].p = p; tj_pin_pool[i].bytes = bytes; tj_pin_pool[i].in_use = 1; break; }
+  pthread_mutex_unlock (&tj_pin_lock);                  /* (no free slot: the buffer is simply not pooled) */
+  return p;
+}
+
+static void
+tj_pinned_put (void *p)
+{
+  int i, found = 0;
+  size_t cached = 0;
+  if (!p) return;
+  pthread_mutex_lock (&tj_pin_lock);
+  for (i = 0; i < TJ_PIN_POOL_SLOTS; i++) if (tj_pin_pool[i].p && !tj_pin_pool[i].in_use) cached += tj_pin_pool[i].bytes;
+  for (i = 0; i < TJ_PIN_POOL_SLOTS; i++)
+    if (tj_pin_pool[i].p == p) {
+      found = 1;
+      if (cached + tj_pin_pool[i].bytes <= (size_t) TJ_PIN_POOL_BYTES) { tj_pin_pool[i].in_use = 0; p = NULL; }
+      else { tj_pin_pool[i].p = NULL; tj_pin_pool[i].bytes = 0; tj_pin_pool[i].in_use = 0; }
+      break;
+    }
+  pthread_mutex_unlock (&tj_pin_lock);
+  (void) found;
+  if (p) tjamd_host_free (p);
+}
+
+static void *tj_sink_alloc (void *ctx, size_t bytes) { (void) ctx; return tj_pinned_get (bytes); }
+static void tj_sink_release (void *ctx, void *p) { (void) ctx; tj_pinned_put (p); }
+static int tj_sink_put (void *ctx, const unsigned char *stream, size_t n_bytes, long n_reads)
+{
+  tj_gpu_sink *g = (tj_gpu_sink *) ctx;
+  (void) n_reads;
+  return tjamd_scan_host (g->dev, stream, n_bytes, g->min_tract_size);
+}
+/* (tjamd_raw_count rather than tjamd_sync: it also brings the exact record counts back, so the device storage is sized
+ * for what the batches really produced, not for the sum of their worst cases) */
+static int tj_sink_sync (void *ctx) { return tjamd_raw_count (((tj_gpu_sink *) ctx)->dev) < 0; }
+
+static int
+tj_feeder_threads (void)
+{
+  const char *e = getenv ("TATAJUBA_AMD_FEEDER_THREADS");
+  long n = e ? atol (e) : sysconf (_SC_NPROCESSORS_ONLN);
+  if (!e && n > 8) n = 8;                               /* the caller may already run one thread per sample */
+  if (n < 1) n = 1;
+  if (n > TJF_MAX_THREADS) n = TJF_MAX_THREADS;
+  return (int) n;
+}
+
+#define TJ_FEEDER_MIN_BYTES (32l << 20)                  /* smaller files: one reader is as fast */
+#define TJ_FEEDER_WINDOW    (128l << 20)
+
 /* ---- file -> device (reference: src/hopo_counter.c:135-157) -------------------------------------------------------- */
 
 hopo_counter
@@ -124,11 +205,31 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
     h->opt = opt;
   }
   if (h->idx_initial) tj_fatal ("This counter has been compared to another; cannot add more reads to it"); /* reference :152 */
+  {                                                     /* big uncompressed file: several readers (feeder.c), same output */
+    struct stat st;
+    const int threads = tj_feeder_threads ();
+    if (threads > 1 && tjf_is_plain_file (filename) == 1 && stat (filename, &st) == 0 && st.st_size >= TJ_FEEDER_MIN_BYTES) {
+      tj_gpu_sink g;
+      tjf_sink sk;
+      long got;
+      g.dev = tj_device_counter (h); g.min_tract_size = opt.min_tract_size;
+      sk.ctx = &g; sk.alloc = tj_sink_alloc; sk.release = tj_sink_release; sk.put = tj_sink_put; sk.sync = tj_sink_sync;
+      got = tjf_parse_file (filename, threads, (size_t) TJ_FEEDER_WINDOW, &sk);
+      if (got == -2 || got == -3) tj_fatal ("%s", got == -2 ? "out of pinned host memory for the feeder" : tjamd_last_error ());
+      if (got >= 0) {
+        n = tjamd_raw_count (g.dev);
+        if (n < 0) tj_fatal ("%s", tjamd_last_error ());
+        tj_priv (h)->n_device = n;
+        h->n_elem = tj_priv (h)->n_host + (int) n;
+        return h;
+      }                                                 /* (-1: cannot open / map -- the one-reader path reports it) */
+    }
+  }
   rd = tjr_open (filename);
   if (!rd) tj_fatal ("cannot open '%s' (the reference leaves gzopen unchecked, src/hopo_counter.c:142; this build stops)", filename);
   dev = tj_device_counter (h);
-  buf[0] = (unsigned char *) tjamd_host_alloc (TJ_BATCH_BYTES);
-  buf[1] = (unsigned char *) tjamd_host_alloc (TJ_BATCH_BYTES);
+  buf[0] = (unsigned char *) tj_pinned_get (TJ_BATCH_BYTES);
+  buf[1] = (unsigned char *) tj_pinned_get (TJ_BATCH_BYTES);
   if (!buf[0] || !buf[1]) tj_fatal ("%s", tjamd_last_error ());
 
   while ((len = tjr_next (rd, &seq)) >= 0) {           /* -2 (bad quality string) ends the file silently, as in the reference */
@@ -142,7 +243,7 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
       continue;
     }
     if (fill + (size_t) len + 1 > TJ_BATCH_BYTES) {     /* batch full: queue copy + scan, parse on into the other buffer */
-      if (in_flight && tjamd_sync (dev)) tj_fatal ("%s", tjamd_last_error ()); /* the other buffer's copy must be done */
+      if (in_flight && tjamd_raw_count (dev) < 0) tj_fatal ("%s", tjamd_last_error ()); /* the other buffer's copy must be done (+ exact counts: see tj_sink_sync) */
       if (tjamd_scan_host (dev, buf[cur], fill, opt.min_tract_size)) tj_fatal ("%s", tjamd_last_error ());
       in_flight = 1; cur ^= 1; fill = 0;
     }
@@ -154,7 +255,7 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
   tjr_close (rd);
   n = tjamd_raw_count (dev);                            /* synchronises the stream */
   if (n < 0) tj_fatal ("%s", tjamd_last_error ());
-  tjamd_host_free (buf[0]); tjamd_host_free (buf[1]);
+  tj_pinned_put (buf[0]); tj_pinned_put (buf[1]);
   tj_priv (h)->n_device = n;
   h->n_elem = tj_priv (h)->n_host + (int) n;
   return h;
@@ -175,6 +276,34 @@ tjamd_read_file_stream (const char *path, unsigned char *out, long capacity, lon
   if (n_reads) *n_reads = n;
   return total;
 }
+
+/* the multi-threaded feeder into host memory (tests compare it with tjamd_read_file_stream) */
+typedef struct { unsigned char *out; long cap, total, n_reads; } tj_mem_sink;
+static void *tj_mem_alloc (void *ctx, size_t bytes) { (void) ctx; return malloc (bytes); }
+static void tj_mem_release (void *ctx, void *p) { (void) ctx; free (p); }
+static int tj_mem_put (void *ctx, const unsigned char *stream, size_t n_bytes, long n_reads)
+{
+  tj_mem_sink *m = (tj_mem_sink *) ctx;
+  if (m->out && m->total + (long) n_bytes <= m->cap) memcpy (m->out + m->total, stream, n_bytes);
+  m->total += (long) n_bytes; m->n_reads += n_reads;
+  return 0;
+}
+
+long
+tjamd_read_file_stream_mt (const char *path, unsigned char *out, long capacity, long *n_reads, int n_threads, long window_bytes)
+{
+  tj_mem_sink m = {out, capacity, 0, 0};
+  tjf_sink sk = {&m, tj_mem_alloc, tj_mem_release, tj_mem_put, NULL};
+  long got;
+  if (tjf_is_plain_file (path) != 1) return tjamd_read_file_stream (path, out, capacity, n_reads);
+  got = tjf_parse_file (path, n_threads, (size_t) (window_bytes > 0 ? window_bytes : TJ_FEEDER_WINDOW), &sk);
+  if (got < 0) return -1;
+  if (n_reads) *n_reads = m.n_reads;
+  return m.total;
+}
+
+/* diagnostic (not in the public header): windows the feeder accepted in its last call, and whether it fell back */
+long tjamd_debug_feeder_stats (long *fell_back) { long w = 0; tjf_last_stats (&w, fell_back); return w; }
 
 /* ---- one sequence, synchronously (reference: src/hopo_counter.c:219-258) ------------------------------------------ */
 

@@ -147,6 +147,99 @@ def test_reader_large_blocks(tmp_path):
     assert m == n and e.tobytes() == s.tobytes()
 
 
+# ---- the multi-threaded feeder (plain files): byte-identical to the one-reader parse, whatever the cut points ---------
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_feeder_matches_single_reader_on_small_cases(tmp_path, name):
+    from tatajuba_amd.capi import read_file_stream_mt
+    path = str(tmp_path / (name + ".txt"))
+    _write(path, CASES[name] * 40)                         # repeated so that tiny windows cut inside and between records
+    exp, m = tj.read_file_stream(path)
+    for threads, window in [(1, 4096), (2, 4096), (3, 5000), (7, 4096), (4, 1 << 20)]:
+        got, n = read_file_stream_mt(path, threads, window)
+        assert n == m and got.tobytes() == exp.tobytes(), (name, threads, window)
+
+
+def _adversarial_file(rng, n_records):
+    """records of every kind the reader knows, with quality strings that look like headers"""
+    out = []
+    for i in range(n_records):
+        L = int(rng.integers(0, 300))
+        seq = "".join(rng.choice(list("ACGTN"), size=L))
+        kind = rng.integers(0, 10)
+        if kind == 0:                                       # FASTA, multi-line
+            w = int(rng.integers(1, 80))
+            out.append(f">fa{i}\n" + "\n".join(seq[j:j + w] for j in range(0, L, w)) + "\n")
+        elif kind == 1:                                     # multi-line FASTQ
+            h = L // 2
+            q = "".join(rng.choice(list("@>+I#!"), size=L))
+            out.append(f"@ml{i}\n{seq[:h]}\n{seq[h:]}\n+\n{q[:h]}\n{q[h:]}\n")
+        elif kind == 2:                                     # quality that starts with '@' / '>' / '+'
+            q = rng.choice(list("@>+")) + "".join(rng.choice(list("@>+I"), size=max(L - 1, 0))) if L else ""
+            out.append(f"@q{i} x\n{seq}\n+\n{q}\n")
+        elif kind == 3:                                     # CRLF
+            out.append(f"@cr{i}\r\n{seq}\r\n+\r\n{'I' * L}\r\n")
+        elif kind == 4:                                     # blank lines between records
+            out.append(f"\n\n@b{i}\n{seq}\n+\n{'I' * L}\n\n")
+        else:
+            out.append(f"@r{i}\n{seq}\n+\n{'F' * L}\n")
+    return "".join(out)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_feeder_matches_single_reader_on_adversarial_files(tmp_path, seed):
+    from tatajuba_amd.capi import read_file_stream_mt
+    rng = np.random.default_rng(seed)
+    txt = _adversarial_file(rng, 6000)
+    if seed == 3:                                           # a record with a bad quality string in the middle: the file ends there
+        cut = len(txt) // 2
+        cut = txt.index("\n@r", cut) + 1
+        txt = txt[:cut] + "@bad\nACGTACGT\n+\nIII\n" + txt[cut:]
+    path = str(tmp_path / "adv.fq")
+    _write(path, txt)
+    exp, m = tj.read_file_stream(path)
+    ora, mo = orc.parse_file_to_stream(path)
+    assert mo == m and ora.tobytes() == exp.tobytes()
+    assert m > 1000
+    for threads, window in [(2, 8192), (5, 20000), (8, 65536), (16, 1 << 20), (3, 1 << 30)]:
+        got, n = read_file_stream_mt(path, threads, window)
+        assert n == m and got.tobytes() == exp.tobytes(), (seed, threads, window)
+
+
+def test_feeder_really_runs_in_parallel_on_ordinary_fastq(tmp_path):
+    import ctypes as C
+    from tatajuba_amd.capi import read_file_stream_mt
+    rng = np.random.default_rng(4)
+    reads = ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(20000)]
+    p = str(tmp_path / "plain.fq")
+    _write(p, "".join(f"@read{i} 1:N:0\n{r}\n+\n{'@' * 150}\n" for i, r in enumerate(reads)))   # worst-case qualities
+    got, n = read_file_stream_mt(p, 8, 1 << 20)
+    assert n == 20000 and got.tobytes() == ("\n".join(reads) + "\n").encode()
+    L = tj.lib()
+    L.tjamd_debug_feeder_stats.restype = C.c_long
+    fb = C.c_long(-1)
+    windows = L.tjamd_debug_feeder_stats(C.byref(fb))
+    assert fb.value == 0 and windows >= 5                   # every window came from the parallel readers
+
+
+def test_feeder_long_records_and_gzip_passthrough(tmp_path):
+    from tatajuba_amd.capi import read_file_stream_mt
+    rng = np.random.default_rng(11)
+    long_seq = "".join(rng.choice(list("ACGT"), size=400000))
+    txt = ">chr1\n" + "\n".join(long_seq[i:i + 60] for i in range(0, len(long_seq), 60)) + "\n" + CASES["fastq4"] * 500 + ">chr2\n" + long_seq + "\n"
+    p = str(tmp_path / "long.fa")
+    _write(p, txt)
+    exp, m = tj.read_file_stream(p)
+    for threads, window in [(4, 8192), (4, 1 << 18), (2, 1 << 22)]:   # records longer than a range: the one-reader fallback
+        got, n = read_file_stream_mt(p, threads, window)
+        assert n == m == 1002 and got.tobytes() == exp.tobytes()
+    g = str(tmp_path / "a.fq.gz")
+    _write(g, CASES["fastq4"] * 100, gz=True)
+    got, n = read_file_stream_mt(g, 4, 4096)
+    exp, m = tj.read_file_stream(g)
+    assert n == m == 200 and got.tobytes() == exp.tobytes()
+
+
 def test_fixture_file_stream(golden_dir, known_answers):
     s, n = tj.read_file_stream(os.path.join(golden_dir, "err1750956.fastq.gz"))
     f = known_answers["file"]

@@ -431,6 +431,32 @@ def test_dropin_large_file_batches(tmp_path):
     h.delete()
 
 
+def test_dropin_plain_fastq_through_the_multithreaded_feeder(tmp_path, monkeypatch):
+    # an uncompressed FASTQ of > 32 MiB goes through feeder.c (several readers over the mapped file); quality strings
+    # that look like headers make its range-start guesses work for their living
+    import ctypes as C
+    monkeypatch.setenv("TATAJUBA_AMD_FEEDER_THREADS", "6")
+    s = tj.synth_stream(250000, 150, 1000000)
+    reads = bytes(s).split(b"\n")[:-1]
+    p = str(tmp_path / "plain.fq")
+    with open(p, "wb") as fh:
+        fh.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, (b"@" if i % 3 else b"I") * len(r)) for i, r in enumerate(reads)))
+    assert os.path.getsize(p) > (32 << 20)
+    opt = tj.Options.defaults(10, 3, 3, True)
+    h = tj.HopoCounter.new_or_append_from_file(None, p, opt)
+    L = tj.lib()
+    L.tjamd_debug_feeder_stats.restype = C.c_long
+    fb = C.c_long(-1)
+    assert L.tjamd_debug_feeder_stats(C.byref(fb)) >= 1 and fb.value == 0
+    o = orc.Oracle(10)
+    o.scan_stream(s, 3)
+    assert h.c.n_elem == o.c.n_elem
+    h.finalise()
+    o.finalise(1, 3)
+    assert h.elems().tobytes() == o.elems().tobytes() and h.c.coverage == o.c.coverage
+    h.delete()
+
+
 @pytest.mark.parametrize("k,m", [(2, 1), (10, 3), (25, 4)])
 def test_many_small_batches_grow_the_bucket_storage(k, m):
     """one counter, hundreds of small scans: the chunk pool and the chunk tables have to grow (and keep what is there)
