@@ -805,8 +805,13 @@ __device__ __forceinline__ void bucket_insert_slow (u64 c0, u64 c1, u32 base, u3
 template <int W>
 struct StageLds
 {
-  static constexpr int S = TJ_STAGE_WORDS / W;           // records
-  u64 rec[TJ_STAGE_WORDS];
+  // a staged record is WS words (the 4th word of a W = 4 record is padding and only exists in HBM); the two-word and
+  // three-word formats get 21 KB instead of 16: fewer, fuller partition passes (their fixed cost is per pass), still three
+  // workgroups per CU
+  static constexpr int WS = (W == 4) ? 3 : W;
+  static constexpr int WORDS = (W == 1) ? TJ_STAGE_WORDS : 2688;
+  static constexpr int S = WORDS / WS;                   // records
+  u64 rec[WORDS];
   u64 gbase[TJ_P];                                      // pool index of the first record of the bucket's run
   u64 gbase2[TJ_P];                                     // pool index of the part of the run that lies in the next chunk
   u32 hist[TJ_P];
@@ -822,6 +827,7 @@ struct StageSink
 {
   static constexpr bool K32 = (W == 1);                 // k <= 12: the scan may use 32-bit k-mer arithmetic
   static constexpr int S = StageLds<W>::S;
+  static constexpr int WS = StageLds<W>::WS;
   static constexpr int R = (S + BLOCK - 1) / BLOCK;     // staged records per thread in a partition pass
   StageLds<W> &L;
   Buckets B; DevCounters *ctr; int k;
@@ -853,7 +859,7 @@ struct StageSink
       u64 w[W];
       pack_raw<W> (c0, c1, base, len10, flag, k, w);
 #pragma unroll
-      for (int j = 0; j < W; j++) L.rec[at * W + j] = w[j];
+      for (int j = 0; j < WS; j++) L.rec[at * WS + j] = w[j];
       L.bin[at] = (unsigned char) bucket_of_key (c0, c1, base, len10);
     }
   }
@@ -865,7 +871,8 @@ struct StageSink
     const u32 n = L.n;
     if (tid < TJ_P) L.hist[tid] = 0;
     lds_barrier ();
-    u64 w[R][W];
+    if (tid == 0) L.n = 0;                              // (everybody has read it; the next appends come after the last barrier below)
+    u64 w[R][WS];
     u32 rk[R], bb[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {                       // my records, and their rank inside their bucket
@@ -874,7 +881,7 @@ struct StageSink
       if (i < n) {
         bb[r] = L.bin[i];
 #pragma unroll
-        for (int j = 0; j < W; j++) w[r][j] = L.rec[i * W + j];
+        for (int j = 0; j < WS; j++) w[r][j] = L.rec[i * WS + j];
         rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
       }
     }
@@ -886,26 +893,14 @@ struct StageSink
       if (lane == 63) L.wsum[wave] = incl;
     }
     lds_barrier ();
+    u32 p0 = 0;
     if (tid < TJ_P) {
       u32 wbase = 0;
       for (int v = 0; v < wave; v++) wbase += L.wsum[v];
       L.offs[tid] = wbase + incl - cnt;
-      if (cnt) {                                        // reserve the bucket's run and find out where it lives
-        const u32 ch = (u32) TJ_CH0 << B.ch_shift;
-        const u32 p0 = atomicAdd (&B.cursors[tid], cnt);
-        bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
-        const u32 j0 = chunk_of_pos (B, p0), j1 = chunk_of_pos (B, p0 + cnt - 1);
-        if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (B, (u32) tid, j0, true, ctr); }
-        L.gbase[tid] = (cur_chunk == TJ_NOCHUNK) ? ~0ull : (u64) cur_chunk * ch + (p0 - j0 * ch);
-        u32 sp = cnt;
-        u64 g2 = ~0ull;
-        if (j1 != j0) {                                 // the run crosses into the next chunk
-          sp = j1 * ch - p0;
-          cur_j = j1; cur_chunk = bucket_chunk_id (B, (u32) tid, j1, true, ctr);
-          if (cur_chunk != TJ_NOCHUNK) g2 = (u64) cur_chunk * ch;
-        }
-        L.split[tid] = sp; L.gbase2[tid] = g2;
-      }
+      // reserve the bucket's run: the global atomic's round trip runs under the LDS permutation below (its result is
+      // first looked at after that)
+      if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
     }
     lds_barrier ();
 #pragma unroll
@@ -913,9 +908,24 @@ struct StageSink
       if (bb[r] != TJ_EMPTY) {
         const u32 d = L.offs[bb[r]] + rk[r];
 #pragma unroll
-        for (int j = 0; j < W; j++) L.rec[d * W + j] = w[r][j];
+        for (int j = 0; j < WS; j++) L.rec[d * WS + j] = w[r][j];
         L.bin[d] = (unsigned char) bb[r];
       }
+    if (tid < TJ_P && cnt) {                            // where the reserved run lives
+      const u32 ch = (u32) TJ_CH0 << B.ch_shift;
+      bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
+      const u32 j0 = chunk_of_pos (B, p0), j1 = chunk_of_pos (B, p0 + cnt - 1);
+      if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (B, (u32) tid, j0, true, ctr); }
+      L.gbase[tid] = (cur_chunk == TJ_NOCHUNK) ? ~0ull : (u64) cur_chunk * ch + (p0 - j0 * ch);
+      u32 sp = cnt;
+      u64 g2 = ~0ull;
+      if (j1 != j0) {                                   // the run crosses into the next chunk
+        sp = j1 * ch - p0;
+        cur_j = j1; cur_chunk = bucket_chunk_id (B, (u32) tid, j1, true, ctr);
+        if (cur_chunk != TJ_NOCHUNK) g2 = (u64) cur_chunk * ch;
+      }
+      L.split[tid] = sp; L.gbase2[tid] = g2;
+    }
     lds_barrier ();
 #pragma unroll
     for (int r = 0; r < R; r++) {                       // sorted slot i -> its place in the bucket's run (coalesced per run)
@@ -926,13 +936,12 @@ struct StageSink
         if (g != ~0ull) {
           u64 *q = B.pool + (g + (o < sp ? o : o - sp)) * W;
 #pragma unroll
-          for (int j = 0; j < W; j++) q[j] = L.rec[i * W + j];
+          for (int j = 0; j < WS; j++) q[j] = L.rec[i * WS + j];
+          if (WS < W) q[W - 1] = 0;
         }
       }
     }
-    lds_barrier ();
-    if (tid == 0) L.n = 0;
-    lds_barrier ();
+    lds_barrier ();                                     // the staging buffer is free again
   }
 
   __device__ __forceinline__ void finish () { partition (); }

@@ -20,7 +20,7 @@ L = tj.lib()
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 s = tj.synth_stream(n_reads, 150, 5_000_000, n_threads=16)
 d = torch.from_numpy(s).cuda()
-c = tj.Counter(10)
+c = tj.Counter(int(os.environ.get("TJ_K", "10")))
 out = (C.c_ulonglong * 32)()
 for it in range(3):
     c.reset()
