@@ -530,8 +530,8 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
         u32 cb = 0, linv = 0, rinv = 0;
         if (e >= 0 && e + k < G::WIN) {               // everything needed is in LDS
           len = e - s + 1;
-          if (Sink::K32) {                            // k <= 12: flanks, masks and k-mers fit 32-bit arithmetic
-            const u32 kb32 = (1u << k) - 1u, km32 = (1u << (2 * k)) - 1u;
+          if (Sink::K32 || k <= 16) {                 // k <= 16: flanks, masks and k-mers fit 32-bit arithmetic (uniform branch)
+            const u32 kb32 = (1u << k) - 1u, km32 = (k >= 16) ? 0xFFFFFFFFu : (1u << (2 * k)) - 1u;
             ok = (((bits32 (T.sent, s - k) | bits32 (T.sent, e + 1)) & kb32) == 0u);
             if (ok && !inval) {
               u32 l32 = bits32 (T.code, 2 * (s - k)) & km32, r32 = bits32 (T.code, 2 * (e + 1)) & km32;
