@@ -1297,13 +1297,14 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
 // the second pool, no barrier in the record loop.
 #define AG2_S        4096
 #define AG2_CLOSE_AT 2560                // typical overshoot: a few keys; worst case one per lane (1024): 87 % full
-#define AG2_R        2                   // records in flight per lane
+#define AG2_R        4                   // records in flight per lane
+#define AG2_VALID    (1ull << 63)        // set in the stored second key word (bits 61-63 of it are not key)
 #define AG2_PENDING  (1ull << 63)
 #define AG2_MARK     (1ull << 63)        // PENDING without a word0 (word0 always has bit 0 set)
 
 struct Agg2Lds
 {
-  u64 k0[AG2_S], k1[AG2_S];
+  ulonglong2 kk[AG2_S];                 // x: claim word (record word 0), y: second key word | VALID
   u32 cnt[2 * AG2_S];                   // per slot: forward / reverse strand
   u32 chunk[AG_NCH];
   u32 n_claimed, n_ovf, total;
@@ -1324,7 +1325,7 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
   u64 *dst = ovf;
 
   while (n > 0) {
-    for (int i = tid; i < AG2_S; i += AG_BLOCK) { L.k0[i] = 0; L.cnt[2 * i] = 0; L.cnt[2 * i + 1] = 0; }
+    for (int i = tid; i < AG2_S; i += AG_BLOCK) { L.kk[i] = make_ulonglong2 (0ull, 0ull); L.cnt[2 * i] = 0; L.cnt[2 * i + 1] = 0; }
     if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; }
     __syncthreads ();
 
@@ -1351,8 +1352,8 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     };
     fetch (0u);
     for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK * AG2_R) {
-      asm volatile ("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]) :: "memory");
-      static_assert (AG2_R == 2, "asm operand list");
+      asm volatile ("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(wn[4]), "+v"(wn[5]), "+v"(wn[6]), "+v"(wn[7]) :: "memory");
+      static_assert (AG2_R == 4, "asm operand list");
       u64 w[2 * AG2_R];
 #pragma unroll
       for (int r = 0; r < 2 * AG2_R; r++) w[r] = wn[r];
@@ -1375,24 +1376,30 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
           else {
             const u64 key1 = w1 & fmask;
             const u32 strand = (u32) (w1 >> 62) & 1u;
-            const u64 a = __hip_atomic_load ((unsigned long long *) &L.k0[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // the claim word and the second key word (stored with its VALID bit; both are zeroed every round) are loaded
+            // together: a published claim word next to a second word that is not valid yet means the two loads straddled
+            // the owner's writes -- look again
+            ulonglong2 v;                                // (two LDS loads in flight together; atomic loads keep the LDS address space)
+            v.x = __hip_atomic_load ((unsigned long long *) &L.kk[slot].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            v.y = __hip_atomic_load ((unsigned long long *) &L.kk[slot].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u64 a = v.x;
             if (a == w0) {
-              if (L.k1[slot] == key1) { atomicAdd (&L.cnt[2 * slot + strand], 1u); adv = true; }
-              else if (++probes >= AG2_S) { left = true; adv = true; }
-              else slot = (slot + 1u) & (AG2_S - 1);
+              if (v.y == (key1 | AG2_VALID)) { atomicAdd (&L.cnt[2 * slot + strand], 1u); adv = true; }
+              else if (v.y & AG2_VALID) {
+                if (++probes >= AG2_S) { left = true; adv = true; }
+                else slot = (slot + 1u) & (AG2_S - 1);
+              }
             }
             else if (a == AG2_MARK) { left = true; adv = true; }
             else if (a == 0ull) {                       // the chain ends here: claim the slot, or MARK it if the table is closed
               const bool closed = __hip_atomic_load (&L.n_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > AG2_CLOSE_AT;
-              unsigned long long expected = 0ull;
-              __hip_atomic_compare_exchange_strong ((unsigned long long *) &L.k0[slot], &expected, closed ? AG2_MARK : (unsigned long long) (w0 | AG2_PENDING),
-                                                    __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (expected == 0ull) {
+              const u64 old = atomicCAS ((unsigned long long *) &L.kk[slot].x, 0ull, closed ? AG2_MARK : (unsigned long long) (w0 | AG2_PENDING));
+              if (old == 0ull) {
                 if (closed) left = true;
                 else {                                  // claimed: publish the second word, then the first
-                  L.k1[slot] = key1;
+                  __hip_atomic_store ((unsigned long long *) &L.kk[slot].y, (unsigned long long) (key1 | AG2_VALID), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                   atomicAdd (&L.n_claimed, 1u);
-                  __hip_atomic_store ((unsigned long long *) &L.k0[slot], (unsigned long long) w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __hip_atomic_store ((unsigned long long *) &L.kk[slot].x, (unsigned long long) w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                   atomicAdd (&L.cnt[2 * slot + strand], 1u);
                 }
                 adv = true;
@@ -1411,7 +1418,12 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
               dst[2 * at] = w0; dst[2 * at + 1] = w1;
             }
           }
-          if (adv) { r++; probes = 0; w0 = w[2]; w1 = w[3]; slot = home (w0, w1); }
+          if (adv) {
+            r++; probes = 0;
+            w0 = (r == 1u) ? w[2] : (r == 2u) ? w[4] : w[6];
+            w1 = (r == 1u) ? w[3] : (r == 2u) ? w[5] : w[7];
+            slot = home (w0, w1);
+          }
         }
       }
     }
@@ -1423,13 +1435,13 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     for (int r = 0; r < AG2_S / AG_BLOCK; r++) {
       const int slot = tid + r * AG_BLOCK;
       metas[r] = 0;
-      if (L.k0[slot] && L.k0[slot] != AG2_MARK) {
+      if (L.kk[slot].x && L.kk[slot].x != AG2_MARK) {
         const u32 cf = L.cnt[2 * slot], cr = L.cnt[2 * slot + 1];
         const u64 flag = (cf ? 1ull : 0ull) | (cr ? 2ull : 0ull);
         const u64 cnt = ((u64) cf + (u64) cr) & 0xFFFFFull;
         const int scnt = (cnt & 0x80000ull) ? (int) cnt - 0x100000 : (int) cnt;
         if (remove_biased ? (flag == 3ull) : (scnt > 1)) {
-          const u64 a = L.k0[slot], b = L.k1[slot];
+          const u64 a = L.kk[slot].x, b = L.kk[slot].y;
           const u64 len10 = ((a >> 2) & 31ull) | (((b >> 56) & 31ull) << 5);
           metas[r] = ((a >> 1) & 1ull) | (len10 << TJ_META_LEN_SHIFT) | (cnt << TJ_META_COUNT_SHIFT) |
                      (0xffeull << TJ_META_MISM_SHIFT) | (flag << TJ_META_FLAG_SHIFT);
@@ -1449,7 +1461,7 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     for (int r = 0; r < AG2_S / AG_BLOCK; r++)
       if (metas[r]) {
         const int slot = tid + r * AG_BLOCK;
-        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (L.k0[slot] >> 7) & m56; q[1] = L.k1[slot] & m56; q[2] = metas[r]; }
+        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (L.kk[slot].x >> 7) & m56; q[1] = L.kk[slot].y & m56; q[2] = metas[r]; }
         else fin->overflow = 1u;
         at++;
       }
