@@ -329,6 +329,9 @@ class Counter:
         self._chkn(lib().tjamd_download_idx(self._h, a.ctypes.data, b.ctypes.data, n))
         return a, b
 
+    def last_scan_launches(self):
+        return int(lib().tjamd_last_scan_launches(self._h))
+
     def last_scan_ms(self):
         return lib().tjamd_last_scan_ms(self._h)
 

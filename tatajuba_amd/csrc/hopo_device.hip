@@ -2244,6 +2244,8 @@ struct DevBuf
   size_t cap = 0;
 };
 
+#define TJ_SCAN_PIECE_TARGET (1ull << 30)               // a long stream is scanned in pieces of 1 GiB; up to 1.5 GiB goes in one launch
+
 // everything the host reads back: one device block, one pinned mirror
 // (each part on cache lines of its own: the scan's workgroups hammer ctr and cursors with atomics)
 struct DevState { alignas (256) DevCounters ctr; alignas (256) FinCounts fin; alignas (256) u32 cursors[TJ_P + 1]; alignas (256) u32 pad[4]; };
@@ -2274,6 +2276,7 @@ struct tjamd_counter
   bool scan_timed = false, fin_timed = false;
   long last_scan_launches = 0;
   unsigned scan_seq = 0;
+  size_t piece_target = TJ_SCAN_PIECE_TARGET;           // TATAJUBA_AMD_SCAN_PIECE (bytes) overrides it: tests
   bool buckets_clean = false;
 };
 
@@ -2311,6 +2314,8 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   const char *bm = getenv ("TATAJUBA_AMD_BIN_MAX");      // test hook: a smaller limit forces the radix path
   if (bm && atoi (bm) >= 1 && atoi (bm) <= BS_RANK_MAX) c->bin_rank_max = (u32) atoi (bm);
+  const char *pc = getenv ("TATAJUBA_AMD_SCAN_PIECE");
+  if (pc && atol (pc) >= 4096) c->piece_target = (size_t) atol (pc);
   const char *sl = getenv ("TATAJUBA_AMD_BUCKET_SLACK");
   if (sl && atof (sl) >= 1.0) c->slack = atof (sl);
   HIPCHK_NULL (hipStreamCreateWithFlags (&c->own_stream, hipStreamNonBlocking));
@@ -2498,13 +2503,10 @@ static int check_scan_args (tjamd_counter *c, int min_tract_size)
   return TJAMD_OK;
 }
 
-extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t n_bytes, int min_tract_size)
+// one launch of the scan over [d_stream, d_stream + n_bytes) (16-byte aligned, starts and ends on read boundaries)
+static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_bytes, int min_tract_size, bool first, bool last)
 {
-  int rc = check_scan_args (c, min_tract_size);
-  if (rc) return rc;
-  if (n_bytes == 0) return TJAMD_OK;
-  if (!d_stream || ((uintptr_t) d_stream & 15u)) return set_err (TJAMD_ERR_ARG, "device stream pointer must be non-null and 16-byte aligned");
-  HIPCHK (hipSetDevice (c->device));
+  int rc = TJAMD_OK;
   if (n_bytes < 64 && d_stream != c->stage.p) {             // the kernels read whole 16-byte chunks: give tiny streams room
     rc = ensure (c->stage, 256, c->stream);
     if (rc) return rc;
@@ -2524,7 +2526,7 @@ extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t
   const Buckets BK = make_buckets (c);
   FixEntry *fix = (FixEntry *) c->fix.p;
   const int par = (int) (c->scan_seq++ & 1u);            // per-launch counters are double-buffered (DevCounters::lc)
-  HIPCHK (hipEventRecord (c->ev_s0, c->stream));
+  if (first) HIPCHK (hipEventRecord (c->ev_s0, c->stream));
   switch (c->W) {
     case 1:
       hipLaunchKernelGGL (scan_bins_kernel<1>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par);
@@ -2540,10 +2542,64 @@ extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t
       break;
   }
   HIPCHK (hipGetLastError ());
-  HIPCHK (hipEventRecord (c->ev_s1, c->stream));
+  if (last) HIPCHK (hipEventRecord (c->ev_s1, c->stream));
   c->scan_timed = true;
-  c->last_scan_launches = 1;
+  c->last_scan_launches = first ? 1 : c->last_scan_launches + 1;
   c->status = -1;
+  return TJAMD_OK;
+}
+
+// A stream is scanned in one launch up to 1.5 x TJ_SCAN_PIECE_TARGET bytes.  A longer one goes piece by piece, each piece cut
+// after a read delimiter that sits on the last byte of a 16-byte line (so that the next piece starts aligned; with reads
+// of any length one turns up within a few reads), and the exact record counts are fetched between pieces: the device
+// storage then follows what the reads really contain instead of the worst case of the whole stream (n / m' records).
+
+__global__ __launch_bounds__ (1024)
+void find_cut_kernel (const uint8_t *__restrict__ seq, unsigned long long from, unsigned long long n, unsigned long long *out)
+{ // *out = smallest p >= from with p % 16 == 15 and seq[p] == '\n', or ~0
+  __shared__ unsigned long long best;
+  if (threadIdx.x == 0) best = ~0ull;
+  __syncthreads ();
+  for (unsigned long long base = from & ~15ull; base < n; base += 1024ull * 16ull) {
+    const unsigned long long p = base + 16ull * threadIdx.x + 15ull;
+    if (p >= from && p < n && seq[p] == (uint8_t) '\n') atomicMin (&best, p);
+    __syncthreads ();
+    if (best != ~0ull) break;
+    __syncthreads ();
+  }
+  if (threadIdx.x == 0) *out = best;
+}
+
+extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t n_bytes, int min_tract_size)
+{
+  int rc = check_scan_args (c, min_tract_size);
+  if (rc) return rc;
+  if (n_bytes == 0) return TJAMD_OK;
+  if (!d_stream || ((uintptr_t) d_stream & 15u)) return set_err (TJAMD_ERR_ARG, "device stream pointer must be non-null and 16-byte aligned");
+  HIPCHK (hipSetDevice (c->device));
+  const size_t piece_target = c->piece_target, piece_max = piece_target + piece_target / 2;
+  if (n_bytes <= piece_max) return scan_device_piece (c, d_stream, n_bytes, min_tract_size, true, true);
+  const uint8_t *seq = (const uint8_t *) d_stream;
+  size_t off = 0;
+  bool first = true;
+  rc = ensure (c->prefix, 64, c->stream);
+  if (rc) return rc;
+  while (off < n_bytes) {
+    size_t end = n_bytes;
+    if (n_bytes - off > piece_max) {
+      unsigned long long cut = ~0ull;
+      hipLaunchKernelGGL (find_cut_kernel, dim3 (1), dim3 (1024), 0, c->stream, seq, (unsigned long long) (off + piece_target), (unsigned long long) n_bytes,
+                          (unsigned long long *) c->prefix.p);
+      HIPCHK (hipMemcpyAsync (&cut, c->prefix.p, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK (hipStreamSynchronize (c->stream));
+      if (cut != ~0ull && cut + 1 < n_bytes) end = (size_t) cut + 1;
+    }
+    rc = scan_device_piece (c, seq + off, end - off, min_tract_size, first, end == n_bytes);
+    if (rc) return rc;
+    if (end < n_bytes && (rc = sync_counters (c))) return rc;     // exact counts: the next piece adds its own worst case to them
+    off = end;
+    first = false;
+  }
   return TJAMD_OK;
 }
 

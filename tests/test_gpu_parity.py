@@ -222,6 +222,27 @@ def test_raw_edge_streams():
         check_raw_multiset(a, 2, 2)
 
 
+def test_long_stream_is_scanned_in_pieces(monkeypatch):
+    # a stream longer than 1.5 pieces is cut after aligned read delimiters and scanned piece by piece with exact counts
+    # in between (the piece size is 1 GiB; the environment hook makes it 200 kB here)
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("TATAJUBA_AMD_SCAN_PIECE", "200000")
+    for k, m, s in [(10, 3, tj.synth_stream(40000, 150, 300000)), (25, 4, tj.synth_stream(3000, 500, 300000, read_len_max=9000)),
+                    (3, 2, np.frombuffer((b"ACGGGTTTACAACCCGT\n" * 70000), np.uint8)),          # 18-byte reads: delimiters on every residue
+                    (4, 3, np.frombuffer((b"ACGGGTTTACAACCCG\n" * 40000) + b"AAAACCCCGGGGTTTT" * 20000 + b"\n", np.uint8))]:
+        d = torch.from_numpy(np.ascontiguousarray(s)).cuda()
+        c = tj.Counter(k)
+        c.scan_device(d.data_ptr(), s.size, m)
+        o = oracle_raw(s, k, m)
+        assert c.raw_count() == o.c.n_elem > 0
+        st = c.finalise(0, 0)
+        o.finalise(0, 0)
+        assert st == o.c.status == 0
+        assert c.download_kept().tobytes() == o.elems().tobytes()
+        assert c.last_scan_launches() >= (3 if s.size > 700000 else 1)
+        c.close()
+
+
 def test_scan_device_pointer_api_and_multiple_batches():
     torch = pytest.importorskip("torch")
     s = tj.synth_stream(30000, 150, 300000)
