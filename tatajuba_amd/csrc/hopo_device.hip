@@ -98,7 +98,9 @@ struct DevCounters
   struct { u64 n_fix; u32 work, pad; } lc[2];
 };
 
+#ifndef TJ_TILE_GROUP
 #define TJ_TILE_GROUP 16
+#endif
 
 struct FixEntry { long long pos; long long len; };
 
@@ -949,7 +951,9 @@ struct StageSink
 
 #define TJ_SB_BLOCK 512
 #define TJ_SB_TILE  8192
+#ifndef TJ_SB_WG_PER_CU
 #define TJ_SB_WG_PER_CU 3               // grid = 3 workgroups per CU: 2 are resident (65 KB of LDS each), the queued third evens out the tail
+#endif
 
 template <int W>
 __global__ __launch_bounds__ (TJ_SB_BLOCK, 6)
