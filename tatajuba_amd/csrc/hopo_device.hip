@@ -4,14 +4,19 @@
 // sort / dedupe / filter / index / coverage (reference: src/hopo_counter.c:339-438).  Integer and byte work only:
 // HBM-bound, no MFMA.  See DESIGN.md for the data layout and the roofline of each kernel.
 //
-// Scan kernel in one paragraph: a workgroup (256 threads = 4 wavefronts) owns a 4 KiB tile of the '\n'-delimited
-// read stream.  Every lane loads 16 bytes (coalesced 1 KiB per wave instruction), classifies them with SWAR bit
-// logic into 2-bit base codes plus three bit-planes (run start, read delimiter, non-ACGTU) and stores those in LDS
-// (2 bits + 3 bits per base instead of 8).  Run starts that can begin a tract of >= m bases are found with shifted
-// ANDs of the run-start plane, compacted into a workgroup-wide candidate list in LDS, and then one lane per
-// candidate finds the run end (count-trailing-zeros on the plane), checks both flanks against the delimiter plane,
-// pulls the two k-mers out of the packed codes with funnel shifts, canonicalises (reverse complement = bit reverse +
-// pair swap of the complemented word) and appends a 24-byte record through a wave-aggregated atomic.
+// Scan kernel in one paragraph: a workgroup (512 threads = 8 wavefronts, three resident per CU) takes tiles of 8 KiB of
+// the '\n'-delimited read stream from a work counter.  The next tile's bytes go from HBM straight into LDS
+// (global_load_lds, 1 KiB per wave instruction) while the current one is worked on.  Every lane classifies its 16 bytes
+// with SWAR bit logic into 2-bit base codes plus three bit-planes (run start, read delimiter, non-ACGTU) kept in LDS.
+// Run starts that begin a tract of >= m bases are found with shifted ANDs of the run-start plane, compacted into a
+// workgroup-wide candidate list, and then one lane per candidate finds the run end (count-trailing-zeros on the plane),
+// checks both flanks against the delimiter plane, pulls the two k-mers out of the packed codes with funnel shifts,
+// canonicalises (reverse complement = bit reverse + pair swap of the complemented word) and appends a packed 8/16/32
+// byte record to an LDS staging buffer, which the workgroup partitions into 256 hash buckets in HBM with one counting
+// sort per few thousand records.  The finalise step aggregates every bucket in an LDS hash table (one workgroup per
+// bucket), orders the survivors with a bin partition + per-wavefront rank sort, and derives the index and the coverage
+// in the same pass.  File map: helpers and tile scan (scan_tiles) -> sinks (located list, bucket staging) -> bucket
+// storage -> aggregation kernels -> radix sort / scans (fallback paths, merge) -> bin kernels -> host layer (tjamd_*).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
