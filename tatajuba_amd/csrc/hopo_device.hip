@@ -1196,21 +1196,36 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       // open; once it is closed (enough keys; a lane looks before each claim, so at most one more key per lane gets
       // in) that slot is MARKed instead, and a MARK ends the chain for everybody: either the key or a MARK wins the
       // slot, so a key is in the table for all of its records or for none (those go back to the bucket's front).
-      // Lanes work through their AG1_R records independently (a wave loops until all its lanes are through): the
+      // Lanes work through their unsettled records independently (a wave loops until all its lanes are through): the
       // iterations of a wave follow the lane with the most probes in total, not the worst probe of every record.
       {
-        u32 r = 0, probes = 0;
-        u64 cur = w[0];
         auto home = [] (u64 key) {
           u32 h = (u32) key ^ __builtin_amdgcn_alignbit ((u32) (key >> 32), (u32) (key >> 32), 17);
           h *= 0x9E3779B1u; h ^= h >> 15;
           return h & (AG1_S / 2 - 1);
         };
+        // first, every record looks at its home pair (straight-line code: the four loads are in flight together) --
+        // that settles all but a few per cent of them
+        u32 todo = 0;
+#pragma unroll
+        for (int r = 0; r < AG1_R; r++) {
+          const u64 cur = w[r];
+          if (((valid >> r) & 1u) && (cur & 3ull) != 3ull) {
+            const u64 key = cur >> 2;
+            const u32 pair = home (key);
+            const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *> (&L.key[2 * pair]);
+            if (kk.x == key || kk.y == key) atomicAdd (&L.cnt[4 * pair + (kk.x == key ? 0u : 2u) + ((u32) (cur >> 1) & 1u)], 1u);
+            else todo |= 1u << r;
+          }
+        }
+        // the rest (new keys, collisions, a closed table) one probe at a time, every lane through its own records
+        u32 probes = 0;
+        u32 r = todo ? (u32) __ffs ((int) todo) - 1u : 0u;
+        u64 cur = (r == 0u) ? w[0] : (r == 1u) ? w[1] : (r == 2u) ? w[2] : w[3];
         u32 pair = home (cur >> 2);
-        while (r < AG1_R) {
+        while (todo) {
           bool adv = false, left = false;
-          if (!((valid >> r) & 1u) || (cur & 3ull) == 3ull) adv = true;
-          else {
+          {
             const u64 key = cur >> 2;
             const u32 strand = (u32) (cur >> 1) & 1u;
             const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *> (&L.key[2 * pair]);
@@ -1234,15 +1249,18 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
               else pair = (pair + 1u) & (AG1_S / 2 - 1);
             }
           }
-          if (left) {                                   // back to the front of the bucket (chunk id cached per lane)
+          if (left) {                                   // to the second pool (chunk ids from LDS)
             const u32 o = atomicAdd (&L.n_ovf, 1u);
             const u32 j = chunk_of_pos (BK, o), oc = chunk_id (j);
             if (oc != TJ_NOCHUNK) dst[(((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift))] = cur;
           }
           if (adv) {
-            r++; probes = 0;
-            cur = (r == 1u) ? w[1] : (r == 2u) ? w[2] : w[3];
-            pair = home (cur >> 2);
+            todo &= todo - 1u; probes = 0;
+            if (todo) {
+              r = (u32) __ffs ((int) todo) - 1u;
+              cur = (r == 1u) ? w[1] : (r == 2u) ? w[2] : w[3];
+              pair = home (cur >> 2);
+            }
           }
         }
       }
