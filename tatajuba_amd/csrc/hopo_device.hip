@@ -1387,8 +1387,6 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       const u32 valid = vn;
       fetch (b0 + AG_BLOCK * AG2_R);
       {
-        u32 r = 0, probes = 0;
-        u64 w0 = w[0], w1 = w[1];
         auto home = [] (u64 a, u64 b) {
           const u64 key1 = b & ~(3ull << 61);
           u32 h = (u32) a ^ __builtin_amdgcn_alignbit ((u32) (a >> 32), (u32) (a >> 32), 19) ^
@@ -1396,11 +1394,28 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
           h *= 0x9E3779B1u; h ^= h >> 15;
           return h & (AG2_S - 1);
         };
+        // first, every record looks at its home slot (straight-line code: the loads of all records are in flight
+        // together); a published claim word with the record's own valid second word settles it
+        u32 todo = 0;
+#pragma unroll
+        for (int q = 0; q < AG2_R; q++) {
+          const u64 a0 = w[2 * q], a1 = w[2 * q + 1];
+          if (((valid >> q) & 1u) && ((a1 >> 61) & 3ull) != 3ull) {
+            const u32 sl = home (a0, a1);
+            const u64 x = __hip_atomic_load ((unsigned long long *) &L.kk[sl].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u64 y = __hip_atomic_load ((unsigned long long *) &L.kk[sl].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (x == a0 && y == ((a1 & fmask) | AG2_VALID)) atomicAdd (&L.cnt[2 * sl + ((u32) (a1 >> 62) & 1u)], 1u);
+            else todo |= 1u << q;
+          }
+        }
+        u32 probes = 0;
+        u32 r = todo ? (u32) __ffs ((int) todo) - 1u : 0u;
+        u64 w0 = (r == 0u) ? w[0] : (r == 1u) ? w[2] : (r == 2u) ? w[4] : w[6];
+        u64 w1 = (r == 0u) ? w[1] : (r == 1u) ? w[3] : (r == 2u) ? w[5] : w[7];
         u32 slot = home (w0, w1);
-        while (r < AG2_R) {
+        while (todo) {
           bool adv = false, left = false;
-          if (!((valid >> r) & 1u) || ((w1 >> 61) & 3ull) == 3ull) adv = true;
-          else {
+          {
             const u64 key1 = w1 & fmask;
             const u32 strand = (u32) (w1 >> 62) & 1u;
             // the claim word and the second key word (stored with its VALID bit; both are zeroed every round) are loaded
@@ -1446,10 +1461,13 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
             }
           }
           if (adv) {
-            r++; probes = 0;
-            w0 = (r == 1u) ? w[2] : (r == 2u) ? w[4] : w[6];
-            w1 = (r == 1u) ? w[3] : (r == 2u) ? w[5] : w[7];
-            slot = home (w0, w1);
+            todo &= todo - 1u; probes = 0;
+            if (todo) {
+              r = (u32) __ffs ((int) todo) - 1u;
+              w0 = (r == 1u) ? w[2] : (r == 2u) ? w[4] : w[6];
+              w1 = (r == 1u) ? w[3] : (r == 2u) ? w[5] : w[7];
+              slot = home (w0, w1);
+            }
           }
         }
       }
