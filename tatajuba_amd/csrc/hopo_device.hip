@@ -489,10 +489,18 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     // ---- phase 2: candidate tract starts among this lane's 16 positions ------------------------------------
     {
       const int p0 = TJ_HL + 16 * tid;
-      const u64 S = bits64 (T.start, p0);
-      u32 cand = (u32) S & 0xFFFFu;
-      if (mprime <= 0) cand &= (u32) (S >> 1);                      // monomer mode: the next position starts a run too
-      for (int j = 1; j < mprime; j++) cand &= ~(u32) (S >> j);     // next m'-1 positions continue the run
+      u32 cand;
+      if (mprime <= 17) {                               // (uniform) the lane's 16 positions + 16 more are all it takes
+        const u32 S = bits32 (T.start, p0);
+        cand = S & 0xFFFFu;
+        if (mprime <= 0) cand &= S >> 1;                              // monomer mode: the next position starts a run too
+        for (int j = 1; j < mprime; j++) cand &= ~(S >> j);           // next m'-1 positions continue the run
+      }
+      else {
+        const u64 S = bits64 (T.start, p0);
+        cand = (u32) S & 0xFFFFu;
+        for (int j = 1; j < mprime; j++) cand &= ~(u32) (S >> j);
+      }
       cand &= ~(u32) reinterpret_cast<unsigned short *> (T.sent)[p0 >> 4];  // a run of delimiters is not a tract
       // one LDS atomic per wavefront (512 same-address atomics serialise): exclusive prefix of the lane counts
       const u32 n = (u32) __popc (cand);
