@@ -489,18 +489,10 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     // ---- phase 2: candidate tract starts among this lane's 16 positions ------------------------------------
     {
       const int p0 = TJ_HL + 16 * tid;
-      u32 cand;
-      if (mprime <= 17) {                               // (uniform) the lane's 16 positions + 16 more are all it takes
-        const u32 S = bits32 (T.start, p0);
-        cand = S & 0xFFFFu;
-        if (mprime <= 0) cand &= S >> 1;                              // monomer mode: the next position starts a run too
-        for (int j = 1; j < mprime; j++) cand &= ~(S >> j);           // next m'-1 positions continue the run
-      }
-      else {
-        const u64 S = bits64 (T.start, p0);
-        cand = (u32) S & 0xFFFFu;
-        for (int j = 1; j < mprime; j++) cand &= ~(u32) (S >> j);
-      }
+      const u64 S = bits64 (T.start, p0);
+      u32 cand = (u32) S & 0xFFFFu;
+      if (mprime <= 0) cand &= (u32) (S >> 1);                      // monomer mode: the next position starts a run too
+      for (int j = 1; j < mprime; j++) cand &= ~(u32) (S >> j);     // next m'-1 positions continue the run
       cand &= ~(u32) reinterpret_cast<unsigned short *> (T.sent)[p0 >> 4];  // a run of delimiters is not a tract
       // one LDS atomic per wavefront (512 same-address atomics serialise): exclusive prefix of the lane counts
       const u32 n = (u32) __popc (cand);
@@ -530,7 +522,9 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
         const int s = T.cand[ci];
         const long gs = g0 + s;
         int e = -1;                                   // run end: first run start after s
-        {
+        const u32 ns32 = bits32 (T.start, s + 1);     // (within 32 positions for all but the longest tracts)
+        if (ns32) e = s + __ffs ((int) ns32) - 1;
+        else {
           const u64 ns = bits64 (T.start, s + 1);
           if (ns) e = s + __ffsll ((long long) ns) - 1;
           else for (int p = s + 65; p < G::WIN; p += 64) {
