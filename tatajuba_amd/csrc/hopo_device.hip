@@ -728,6 +728,14 @@ __device__ __forceinline__ u32 bucket_of_key (u64 c0, u64 c1, u32 base, u32 len1
   return (h ^ (h >> 8)) & 255u;
 }
 
+// the same for k-mers that fit 32 bits (identical value: dot products with a zero word leave the accumulator as it is)
+__device__ __forceinline__ u32 bucket_of_key32 (u32 c0, u32 c1, u32 base, u32 len10)
+{
+  u32 h = __builtin_amdgcn_udot4 (c0, 0x6D2B4F0Bu, base | (len10 << 2), false);
+  h = __builtin_amdgcn_udot4 (c1, 0xC5A34D17u, h, false);
+  return (h ^ (h >> 8)) & 255u;
+}
+
 #define TJ_P        256                 // hash buckets
 #define TJ_PBITS    8
 #define TJ_STAGE_WORDS 2048             // 64-bit words of records a workgroup stages in LDS between partition passes
@@ -869,7 +877,8 @@ struct StageSink
       pack_raw<W> (c0, c1, base, len10, flag, k, w);
 #pragma unroll
       for (int j = 0; j < WS; j++) L.rec[at * WS + j] = w[j];
-      L.bin[at] = (unsigned char) bucket_of_key (c0, c1, base, len10);
+      // (one-word records have k <= 12: the high halves of the k-mers are 0 and their two dot products add nothing)
+      L.bin[at] = (unsigned char) (W == 1 ? bucket_of_key32 ((u32) c0, (u32) c1, base, len10) : bucket_of_key (c0, c1, base, len10));
     }
   }
 
