@@ -1964,49 +1964,62 @@ __global__ void ctx_write_kernel (long n1, const u32 *__restrict__ ctxpos, const
 }
 
 // coverage: pooled 31-bit-truncated flanks weighted by count, largest pooled weight wins (reference
-// src/hopo_counter.c:419-438).  Open-addressing table in HBM; a slot holds key + 1, 0 = empty.
-__device__ __forceinline__ void cov_add_from (u32 key31, u32 slot, int w, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
+// src/hopo_counter.c:419-438).  Open-addressing table in HBM, one 64-bit word per slot: key + 1 in the high half (0 =
+// empty), the pooled weight in the low half.  A new key and its first weight go in with ONE compare-and-swap (the
+// memory-side atomics are what this step runs at); a key that is already there gets a 32-bit add on the low half
+// (wraps like the reference's int, never carries into the key).
+__device__ __forceinline__ u64 cov_word (u32 key31, int w) { return ((u64) (key31 + 1u) << 32) | (u64) (u32) w; }
+
+__device__ __forceinline__ void cov_add_from (u32 key31, u32 slot, int w, u64 *__restrict__ tab, int log2t)
 {
-  const u32 tmask = (1u << log2t) - 1u, stored = key31 + 1u;
+  const u32 tmask = (1u << log2t) - 1u;
   for (u32 probe = 0; probe <= tmask; probe++) {
-    const u32 old = atomicCAS (&keys[slot], 0u, stored);
-    if (old == 0u || old == stored) { atomicAdd (&sums[slot], w); break; }
+    const u64 old = atomicCAS ((unsigned long long *) &tab[slot], 0ull, (unsigned long long) cov_word (key31, w));
+    if (old == 0ull) break;
+    if ((u32) (old >> 32) == key31 + 1u) { atomicAdd (reinterpret_cast<u32 *> (&tab[slot]), (u32) w); break; }   // (little endian: low half first)
     slot = (slot + 1u) & tmask;
   }
 }
 
-__device__ __forceinline__ void cov_add (u32 key31, int w, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
+__device__ __forceinline__ void cov_add (u32 key31, int w, u64 *__restrict__ tab, int log2t)
 {
-  cov_add_from (key31, (key31 * 2654435761u) >> (32 - log2t), w, keys, sums, log2t);
+  cov_add_from (key31, (key31 * 2654435761u) >> (32 - log2t), w, tab, log2t);
 }
 
-// two keys at once: both compare-and-swaps are in flight together (the round trip to the memory-side atomics dominates)
-__device__ __forceinline__ void cov_add2 (u32 ka, u32 kb, int w, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
+// two keys at once: both compare-and-swaps are in flight together
+__device__ __forceinline__ void cov_add2 (u32 ka, u32 kb, int w, u64 *__restrict__ tab, int log2t)
 {
-  const u32 tmask = (1u << log2t) - 1u, sa = ka + 1u, sb = kb + 1u;
-  u32 pa = (ka * 2654435761u) >> (32 - log2t), pb = (kb * 2654435761u) >> (32 - log2t);
-  const u32 oa = atomicCAS (&keys[pa], 0u, sa), ob = atomicCAS (&keys[pb], 0u, sb);
-  if (oa == 0u || oa == sa) atomicAdd (&sums[pa], w);
-  else cov_add_from (ka, (pa + 1u) & tmask, w, keys, sums, log2t);
-  // (if both keys are equal and met an empty slot, the second CAS has seen the first one's key: still one slot)
-  if (ob == 0u || ob == sb) atomicAdd (&sums[pb], w);
-  else cov_add_from (kb, (pb + 1u) & tmask, w, keys, sums, log2t);
+  const u32 tmask = (1u << log2t) - 1u;
+  const u32 pa = (ka * 2654435761u) >> (32 - log2t), pb = (kb * 2654435761u) >> (32 - log2t);
+  const u64 oa = atomicCAS ((unsigned long long *) &tab[pa], 0ull, (unsigned long long) cov_word (ka, w));
+  const u64 ob = atomicCAS ((unsigned long long *) &tab[pb], 0ull, (unsigned long long) cov_word (kb, w));
+  if (oa != 0ull) {
+    if ((u32) (oa >> 32) == ka + 1u) atomicAdd (reinterpret_cast<u32 *> (&tab[pa]), (u32) w);
+    else cov_add_from (ka, (pa + 1u) & tmask, w, tab, log2t);
+  }
+  // (both keys equal and the slot empty: the second compare-and-swap has seen the first one's word and adds to it)
+  if (ob != 0ull) {
+    if ((u32) (ob >> 32) == kb + 1u) atomicAdd (reinterpret_cast<u32 *> (&tab[pb]), (u32) w);
+    else cov_add_from (kb, (pb + 1u) & tmask, w, tab, log2t);
+  }
 }
 
-__global__ void cov_insert_kernel (const u64 *__restrict__ kept, long n1, u32 *__restrict__ keys, int *__restrict__ sums, int log2t)
+__global__ void cov_insert_kernel (const u64 *__restrict__ kept, long n1, u64 *__restrict__ tab, int log2t)
 {
   for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < 2 * n1; i += (long) gridDim.x * blockDim.x) {
     const long r = (i < n1) ? i : i - n1;
-    cov_add ((u32) (kept[3 * r + (i < n1 ? 0 : 1)] & 0x7FFFFFFFull), meta_count (kept[3 * r + 2]), keys, sums, log2t);
+    cov_add ((u32) (kept[3 * r + (i < n1 ? 0 : 1)] & 0x7FFFFFFFull), meta_count (kept[3 * r + 2]), tab, log2t);
   }
 }
 
 // largest pooled weight of the table slice this workgroup looks at -> atomicMax (one atomic per workgroup)
-__device__ __forceinline__ void cov_max_part (const u32 *__restrict__ keys, const int *__restrict__ sums, long t, int *result, int *s_best)
+__device__ __forceinline__ void cov_max_part (const u64 *__restrict__ tab, long t, int *result, int *s_best)
 {
   int best = INT_MIN;
-  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < t; i += (long) gridDim.x * blockDim.x)
-    if (keys[i] != 0u) best = max (best, sums[i]);
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < t; i += (long) gridDim.x * blockDim.x) {
+    const u64 v = tab[i];
+    if (v >> 32) best = max (best, (int) (u32) v);
+  }
   for (int o = 32; o > 0; o >>= 1) best = max (best, __shfl_down (best, o));
   if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
   __syncthreads ();
@@ -2017,10 +2030,10 @@ __device__ __forceinline__ void cov_max_part (const u32 *__restrict__ keys, cons
 }
 
 __global__ __launch_bounds__ (256)
-void cov_max_kernel (const u32 *__restrict__ keys, const int *__restrict__ sums, long t, int *result)
+void cov_max_kernel (const u64 *__restrict__ tab, long t, int *result)
 {
   __shared__ int s_best[4];
-  cov_max_part (keys, sums, t, result, s_best);
+  cov_max_part (tab, t, result, s_best);
 }
 
 // One wavefront per bin: the bin's records go to LDS, every lane counts the records that come before its own, and that
@@ -2033,7 +2046,7 @@ void cov_max_kernel (const u32 *__restrict__ keys, const int *__restrict__ sums,
 
 __global__ __launch_bounds__ (64 * BSI_WAVES)
 void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, const u32 *__restrict__ binstart, int nbins, const FinCounts *fin,
-                            int min_coverage, u32 *__restrict__ cov_keys, int *__restrict__ cov_sums, int log2t,
+                            int min_coverage, u64 *__restrict__ cov_tab, int log2t,
                             u32 *__restrict__ binctx, u32 *__restrict__ tstart, u32 *__restrict__ tend)
 {
   __shared__ u64 rec[BSI_WAVES][3 * BS_RANK_MAX];
@@ -2059,7 +2072,7 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
       if (t < s) {
         const u64 a0 = R[3 * t], a1 = R[3 * t + 1], am = R[3 * t + 2];
         const int w = meta_count (am);
-        cov_add2 ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_keys, cov_sums, log2t);
+        cov_add2 ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t);
         u32 rank = 0, ctx_before = 0, ctx_size = 0;
         int depth = 0;
         for (u32 j = 0; j < s; j++) {
@@ -2108,7 +2121,7 @@ void bin_ctx_scan_kernel (const u32 *__restrict__ binctx, int nbins, u32 *__rest
 __global__ __launch_bounds__ (256)
 void bin_ctx_write_kernel (const u32 *__restrict__ binstart, const u32 *__restrict__ binctx, const u32 *__restrict__ binout, int nbins,
                            const u32 *__restrict__ tstart, const u32 *__restrict__ tend, int *__restrict__ idx_initial, int *__restrict__ idx_final,
-                           const u32 *__restrict__ cov_keys, const int *__restrict__ cov_sums, long t, FinCounts *fin)
+                           const u64 *__restrict__ cov_tab, long t, FinCounts *fin)
 {
   __shared__ int s_best[4];
   if (fin->sort_fallback) return;
@@ -2117,7 +2130,7 @@ void bin_ctx_write_kernel (const u32 *__restrict__ binstart, const u32 *__restri
     const u32 cnt = binctx[bin], st = binstart[bin], o0 = binout[bin];
     for (u32 o = lane; o < cnt; o += 64) { idx_initial[o0 + o] = (int) tstart[st + o]; idx_final[o0 + o] = (int) tend[st + o]; }
   }
-  cov_max_part (cov_keys, cov_sums, t, &fin->coverage, s_best);
+  cov_max_part (cov_tab, t, &fin->coverage, s_best);
 }
 
 // ---- cross-sample merge on the bins --------------------------------------------------------------------------------
@@ -2874,13 +2887,12 @@ static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
   const long t = 1l << log2t;
   rc = ensure (c->cov, (size_t) t * 8, c->stream);
   if (rc) return rc;
-  u32 *ckeys = (u32 *) c->cov.p;
-  int *csums = (int *) c->cov.p + t;
+  u64 *ctab = (u64 *) c->cov.p;
   HIPCHK (hipMemsetAsync (c->cov.p, 0, (size_t) t * 8, c->stream));
   hipLaunchKernelGGL (set_int_kernel, dim3 (1), dim3 (1), 0, c->stream, &c->d_fin->coverage, INT_MIN);
-  hipLaunchKernelGGL (cov_insert_kernel, dim3 (grid_for (2 * n1)), dim3 (256), 0, c->stream, kept, n1, ckeys, csums, log2t);
+  hipLaunchKernelGGL (cov_insert_kernel, dim3 (grid_for (2 * n1)), dim3 (256), 0, c->stream, kept, n1, ctab, log2t);
   HIPCHK (hipGetLastError ());
-  hipLaunchKernelGGL (cov_max_kernel, dim3 (std::min<unsigned> (grid_for (t), 256u)), dim3 (256), 0, c->stream, (const u32 *) ckeys, (const int *) csums, t, &c->d_fin->coverage);
+  hipLaunchKernelGGL (cov_max_kernel, dim3 (std::min<unsigned> (grid_for (t), 256u)), dim3 (256), 0, c->stream, (const u64 *) ctab, t, &c->d_fin->coverage);
   HIPCHK (hipGetLastError ());
   HIPCHK (hipEventRecord (c->ev_f1, c->stream));
   c->fin_timed = true;
@@ -2912,8 +2924,7 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
   if (rc) return rc;
   u32 *bins = (u32 *) c->bins.p, *binstart = (u32 *) c->binstart.p, *binctx = (u32 *) c->binctx.p, *binout = binctx + nbins;
   u32 *tstart = (u32 *) c->headpos.p, *tend = (u32 *) c->outpos.p;
-  u32 *ckeys = (u32 *) c->cov.p;
-  int *csums = (int *) c->cov.p + t;
+  u64 *ctab = (u64 *) c->cov.p;
   if (!c->bins_zeroed) HIPCHK (hipMemsetAsync (bins, 0, (size_t) BS_MAXBINS * 4, c->stream));
   c->bins_zeroed = false;
   hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n1, c->k, nbits, bins,
@@ -2922,10 +2933,10 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
   hipLaunchKernelGGL (bin_scatter_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins);
   hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 16384)), dim3 (64 * BSI_WAVES), 0, c->stream,
                       (const u64 *) c->alt.p, (u64 *) c->kept.p, (const u32 *) binstart, nbins, (const FinCounts *) c->d_fin, min_coverage,
-                      ckeys, csums, log2t, binctx, tstart, tend);
+                      ctab, log2t, binctx, tstart, tend);
   hipLaunchKernelGGL (bin_ctx_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, (const u32 *) binctx, nbins, binout, c->d_fin);
   hipLaunchKernelGGL (bin_ctx_write_kernel, dim3 (256), dim3 (256), 0, c->stream, (const u32 *) binstart, (const u32 *) binctx, (const u32 *) binout, nbins,
-                      (const u32 *) tstart, (const u32 *) tend, (int *) c->idx_i.p, (int *) c->idx_f.p, (const u32 *) ckeys, (const int *) csums, t, c->d_fin);
+                      (const u32 *) tstart, (const u32 *) tend, (int *) c->idx_i.p, (int *) c->idx_f.p, (const u64 *) ctab, t, c->d_fin);
   HIPCHK (hipGetLastError ());
   HIPCHK (hipEventRecord (c->ev_f1, c->stream));
   c->fin_timed = true;
