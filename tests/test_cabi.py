@@ -266,3 +266,25 @@ def test_synth_stream_properties():
     v1 = tj.synth_stream(2000, 150, 200000, variant_seed=1)
     v2 = tj.synth_stream(2000, 150, 200000, variant_seed=2)
     assert v1.tobytes() != v2.tobytes() and v1.tobytes() != a[:v1.size].tobytes()
+
+
+# ---- a plain C program against include/tatajuba_hopo.h (examples/count_tracts.c) ---------------------------------------
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "count_tracts")
+    libdir = os.path.join(root, "tatajuba_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "count_tracts.c"),
+                           "-L", libdir, "-ltatajuba_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_c_example_links_and_fails_loudly_without_gpu(tmp_path, golden_dir):
+    import subprocess
+    tj.lib()                                                # (builds the library if need be)
+    exe = _build_c_example(tmp_path)
+    if tj.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu test")
+    r = subprocess.run([exe, os.path.join(golden_dir, "err1750956.fastq.gz"), "-k", "10", "-m", "3"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr and "no CPU fallback" in r.stderr

@@ -543,6 +543,23 @@ def test_merge_samples_device(monkeypatch, k, n_samples, force_radix):
         c.close()
 
 
+def test_c_example_program_on_the_reference_fixture(tmp_path, golden_dir, known_answers):
+    # examples/count_tracts.c: a C caller of the drop-in API, compiled with gcc against include/ and the shared library
+    import subprocess
+    from tests.test_cabi import _build_c_example
+    exe = _build_c_example(tmp_path)
+    path = os.path.join(golden_dir, known_answers["file"]["path"])
+    r = subprocess.run([exe, path, "-k", "10", "-m", "3", "-c", "5", "-b", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    cs = [c for c in known_answers["file"]["cases"] if (c["k"], c["m"], c["min_coverage"], c["remove_biased"]) == (10, 3, 5, 1)][0]
+    assert f": {cs['raw']} homopolymer tracts" in r.stdout
+    assert f"context histogram: {cs['n_elem']} (context, length) entries, {cs['n_idx']} contexts reach coverage 5, coverage estimate {cs['coverage']}" in r.stdout
+    # paired: the same file as R1 and R2
+    r = subprocess.run([exe, path, path, "-k", "10", "-m", "3"], capture_output=True, text=True, timeout=120)
+    p2 = known_answers["file"]["paired_same_file_twice_k10_m3"]
+    assert r.returncode == 0 and f": {p2['raw']} homopolymer tracts" in r.stdout and f"context histogram: {p2['n_elem']} " in r.stdout
+
+
 # ---- full benchmark size: size-independent properties ---------------------------------------------------------------
 
 def _revcomp_stream(s, L):
