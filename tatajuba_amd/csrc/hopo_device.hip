@@ -469,12 +469,26 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     const long nt = (tile + 1 < grp_end) ? tile + 1 : (long) T.grp[gpar ^ 1u];
     {
       if (nt < n_tiles) {
+        const long ng0 = nt * (long) TILE - TJ_HL;
+        if (ng0 >= 16 && ng0 + (long) G::WIN <= n_bytes) {      // (uniform) the whole window and the chunk in front are inside: no per-lane checks
+          const uint8_t *pl = seq + ng0 + 16l * tid;
 #pragma unroll
-        for (int i = 0; i < G::NLOAD; i++) {
-          const int c = tid + i * BLOCK;
-          if (c < G::NCHUNK) {
-            issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * c, &raw[c - (tid & 63)]);
-            if ((tid & 63) == 0) issue_chunk (seq, n_bytes, nt * (long) TILE - TJ_HL + 16l * (c - 1), &raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)]);
+          for (int i = 0; i < G::NLOAD; i++) {
+            const int c = tid + i * BLOCK;
+            if (c < G::NCHUNK) {
+              __builtin_amdgcn_global_load_lds ((gptr_t) (pl + 16l * i * BLOCK), (lptr_t) &raw[c - (tid & 63)], 16, 0, 0);
+              if ((tid & 63) == 0) __builtin_amdgcn_global_load_lds ((gptr_t) (pl + 16l * i * BLOCK - 16), (lptr_t) &raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)], 16, 0, 0);
+            }
+          }
+        }
+        else {
+#pragma unroll
+          for (int i = 0; i < G::NLOAD; i++) {
+            const int c = tid + i * BLOCK;
+            if (c < G::NCHUNK) {
+              issue_chunk (seq, n_bytes, ng0 + 16l * c, &raw[c - (tid & 63)]);
+              if ((tid & 63) == 0) issue_chunk (seq, n_bytes, ng0 + 16l * (c - 1), &raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)]);
+            }
           }
         }
       }
