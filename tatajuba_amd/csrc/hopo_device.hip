@@ -1076,58 +1076,12 @@ __global__ void table_relayout_kernel (const u32 *__restrict__ old, u32 old_maxj
 // aggregation: one workgroup per bucket streams its raw records through an LDS hash table keyed by
 // (base, context, stored length), counting the two strands separately (reference: the qsort + run-length pass of
 // src/hopo_counter.c:351-365), then applies the strand / singleton filter (:367-374) and appends the survivors, as
-// 24-byte records carrying count and canon_flag, to the kept list.  A table that fills up closes (no new keys, absent
-// keys go back to the front of the bucket) and the leftovers are aggregated in further rounds; a key is always
-// entirely in one round, so rounds never split a count.
+// 24-byte records carrying count and canon_flag, to the kept list.  A table that fills up closes (no new keys; records
+// of absent keys go to a second pool) and the leftovers are aggregated in further rounds; a key is always entirely in
+// one round, so rounds never split a count.  One kernel per record width; aggregate1_kernel carries the commentary.
 
-#define AG_S        4096                // table slots
-#define AG_CLOSE_AT 1280                // stop admitting new keys beyond this many (one more batch may add 1024): load stays < 60 %
 #define AG_BLOCK    1024
 #define AG_NCH      512                 // chunk ids of a bucket cached in LDS (longer buckets look the rest up in the table)
-
-
-struct AggLds
-{
-  u64 k0[AG_S];
-  u64 k1[AG_S];
-  u32 tag[AG_S];                        // 0 empty; (hash[63:34] << 2) | 1 published; | 2 while its key is being written
-  u32 k2[AG_S];                         // base | stored length << 2
-  u32 cf[AG_S];                         // occurrences as read (canon_flag 1)
-  u32 cr[AG_S];                         // occurrences reverse-complemented (canon_flag 2)
-  u32 n_claimed, n_ovf, closed[2], total;
-  u32 wsum[AG_BLOCK / 64];
-};
-
-__device__ __forceinline__ bool agg_insert (AggLds &L, u64 c0, u64 c1, u32 k2, u32 flag, u64 h, bool closed)
-{ // true = counted; false = key absent from a closed table
-  const u32 mytag = ((u32) (h >> 32) & ~3u) | 1u;
-  u32 slot = (u32) (h >> TJ_PBITS) & (AG_S - 1);
-  for (u32 probes = 0; probes < AG_S;) {
-    u32 t;
-    if (!closed) {
-      u32 expected = 0u;
-      __hip_atomic_compare_exchange_strong (&L.tag[slot], &expected, mytag | 2u, __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      t = expected;                                     // previous value (0 = we own the slot now)
-    }
-    else t = __hip_atomic_load (&L.tag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (t == 0u) {
-      if (closed) return false;
-      L.k0[slot] = c0; L.k1[slot] = c1; L.k2[slot] = k2;
-      atomicAdd (&L.n_claimed, 1u);
-      __hip_atomic_store (&L.tag[slot], mytag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // publish
-      atomicAdd ((flag & 2u) ? &L.cr[slot] : &L.cf[slot], 1u);
-      return true;
-    }
-    if (t == (mytag | 2u)) continue;                    // same tag, key still being written by its owner: look again
-    if (t == mytag && L.k0[slot] == c0 && L.k1[slot] == c1 && L.k2[slot] == k2) {
-      atomicAdd ((flag & 2u) ? &L.cr[slot] : &L.cf[slot], 1u);
-      return true;
-    }
-    slot = (slot + 1u) & (AG_S - 1);
-    probes++;
-  }
-  return false;
-}
 
 // ---- W = 1 (k <= 12): the whole reduction key is the record word without its strand flag, so one 64-bit LDS
 // compare-and-swap per probe decides "new key / same key / other key" -- no tag, no publish step, no key read-back.
@@ -1543,107 +1497,166 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
   }
 }
 
-template <int W>
-__global__ __launch_bounds__ (AG_BLOCK)
-void aggregate_kernel (Buckets BK, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+// ---- W = 4 (k <= 32): the k-mers fill their 64-bit words, so the claim word is made of the small key part and a hash:
+// 1 | (base | length << 2) << 1 | 50 hash bits << 13 (never 0, bit 63 free).  Same protocol as aggregate2_kernel; a match
+// needs the claim word AND both k-mers, and because the k-mer words have no room for a VALID bit, a claim-word match
+// whose k-mers differ -- or are both 0, the cleared state -- is confirmed with a second look before it counts.
+#define AG4_S        4096
+#define AG4_CLOSE_AT 2560
+#define AG4_R        2
+#define AG4_PENDING  (1ull << 63)
+#define AG4_MARK     (1ull << 63)
+
+struct Agg4Lds
 {
-  __shared__ AggLds L;
+  u64 cw[AG4_S], c0[AG4_S], c1[AG4_S];
+  u32 cnt[2 * AG4_S];
+  u32 chunk[AG_NCH];
+  u32 n_claimed, n_ovf, total;
+  u32 wsum[AG_BLOCK / 64];
+};
+
+__global__ __launch_bounds__ (AG_BLOCK)
+void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+{
+  __shared__ Agg4Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 bkt = blockIdx.x;
   u32 n = BK.cursors[bkt];
+  if (n) for (u32 j = (u32) tid; j <= chunk_of_pos (BK, n - 1u) && j < AG_NCH; j += AG_BLOCK) L.chunk[j] = bucket_chunk_id (BK, bkt, j, false, nullptr);
+  auto chunk_id = [&] (u32 j) { return j < AG_NCH ? L.chunk[j] : bucket_chunk_id (BK, bkt, j, false, nullptr); };
+  const u64 *src = BK.pool;
+  u64 *dst = ovf;
+  auto ld = [] (u64 *p) { return (u64) __hip_atomic_load ((unsigned long long *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
   while (n > 0) {
-    for (int i = tid; i < AG_S; i += AG_BLOCK) { L.tag[i] = 0; L.cf[i] = 0; L.cr[i] = 0; }
-    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.closed[0] = L.closed[1] = 0; }
+    for (int i = tid; i < AG4_S; i += AG_BLOCK) { L.cw[i] = 0; L.c0[i] = 0; L.c1[i] = 0; L.cnt[2 * i] = 0; L.cnt[2 * i + 1] = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; }
     __syncthreads ();
 
-    u64 wn[W];                                          // records are fetched one batch ahead of their use
-    bool vn = false;
-    u32 cj = TJ_EMPTY, cc = TJ_NOCHUNK;                 // chunk this lane is reading from (changes once per chunk)
-    auto fetch = [&] (u32 idx) {
-      vn = false;
-      if (idx < n) {
-        const u32 j = chunk_of_pos (BK, idx);
-        if (j != cj) { cj = j; cc = bucket_chunk_id (BK, bkt, j, false, nullptr); }
-        if (cc != TJ_NOCHUNK) {
-          const u64 at = (((u64) cc * TJ_CH0) << BK.ch_shift) + (idx - ((j * TJ_CH0) << BK.ch_shift));
-          vn = true;
+    u64 wn[3 * AG4_R];                                  // (the fourth word of a record is padding)
+    u32 vn = 0;
+    auto fetch = [&] (u32 b0) {                         // see aggregate1_kernel: a round lies in at most two chunks
+      vn = 0;
 #pragma unroll
-          for (int j2 = 0; j2 < W; j2++) wn[j2] = BK.pool[at * W + j2];
+      for (int r = 0; r < 3 * AG4_R; r++) wn[r] = 0;
+      if (b0 >= n) return;
+      const u32 ch = (u32) TJ_CH0 << BK.ch_shift;
+      const u32 j0 = chunk_of_pos (BK, b0), bound = (j0 + 1u) * ch;
+      const u32 c0 = chunk_id (j0), c1 = (bound < n) ? chunk_id (j0 + 1u) : TJ_NOCHUNK;
+      const u64 off0 = (u64) c0 * ch - (u64) j0 * ch, off1 = (u64) c1 * ch - (u64) bound;
+#pragma unroll
+      for (int r = 0; r < AG4_R; r++) {
+        const u32 idx = b0 + (u32) r * AG_BLOCK + (u32) tid;
+        const bool hi = idx >= bound;
+        if (idx < n && (hi ? c1 : c0) != TJ_NOCHUNK) {
+          const u64 *p = src + 4 * ((hi ? off1 : off0) + idx);
+          const ulonglong2 v = *reinterpret_cast<const ulonglong2 *> (p);
+          vn |= 1u << r; wn[3 * r] = v.x; wn[3 * r + 1] = v.y; wn[3 * r + 2] = p[2];
         }
       }
     };
-    fetch ((u32) tid);
-    u32 par = 0;
-    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK, par ^= 1u) {
-      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's record has arrived (fetched one batch ago)
-      u64 w[W];
+    fetch (0u);
+    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK * AG4_R) {
+      asm volatile ("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(wn[4]), "+v"(wn[5]) :: "memory");
+      static_assert (AG4_R == 2, "asm operand list");
+      u64 w[3 * AG4_R];
 #pragma unroll
-      for (int j = 0; j < W; j++) w[j] = wn[j];
-      const bool valid = vn;
-      fetch (b0 + AG_BLOCK + tid);                      // leftovers are written below b0 + AG_BLOCK: never where this reads
-      // two barriers per batch: see aggregate1_kernel
-      if (tid == 0) L.closed[par] = (L.n_claimed > AG_CLOSE_AT) ? 1u : 0u;
-      lds_barrier ();
-      const bool closed = L.closed[par] != 0u;
-      if (valid) {
-        u64 c0, c1; u32 base, len10, flag;
-        unpack_raw<W> (w, k, c0, c1, base, len10, flag);
-        if (flag != 3u && !agg_insert (L, c0, c1, base | (len10 << 2), flag, hash_key (c0, c1, base, len10), closed)) {
-          const u32 o = atomicAdd (&L.n_ovf, 1u);        // o <= records consumed so far: never ahead of the reads
-          const u64 at = bucket_slot (BK, bkt, o, false, nullptr);
-          if (at != ~0ull) {
+      for (int r = 0; r < 3 * AG4_R; r++) w[r] = wn[r];
+      const u32 valid = vn;
+      fetch (b0 + AG_BLOCK * AG4_R);
+      u32 todo = 0;
 #pragma unroll
-            for (int j = 0; j < W; j++) BK.pool[at * W + j] = w[j];
+      for (int q = 0; q < AG4_R; q++) if (((valid >> q) & 1u) && ((w[3 * q + 2] >> 12) & 3ull) != 3ull) todo |= 1u << q;
+      u32 probes = 0;
+      while (todo) {
+        const u32 r = (u32) __ffs ((int) todo) - 1u;
+        const u64 c0 = r ? w[3] : w[0], c1 = r ? w[4] : w[1], m2 = r ? w[5] : w[2];
+        const u32 k2 = (u32) m2 & 0xFFFu, strand = (u32) (m2 >> 13) & 1u;     // flag 1 = as read, 2 = reverse-complemented
+        const u64 hk = hash_key (c0, c1, k2 & 3u, k2 >> 2);
+        const u64 cw = 1ull | ((u64) k2 << 1) | ((hk >> 14) << 13);
+        u32 slot = ((u32) hk + probes) & (AG4_S - 1);     // (linear probing: the probe count is the offset)
+        bool adv = false, left = false;
+        const u64 a = ld (&L.cw[slot]);
+        u64 x0 = ld (&L.c0[slot]), x1 = ld (&L.c1[slot]);
+        if (a == cw) {
+          bool eq = (x0 == c0) & (x1 == c1);
+          if (!eq || (c0 | c1) == 0ull) { x0 = ld (&L.c0[slot]); x1 = ld (&L.c1[slot]); eq = (x0 == c0) & (x1 == c1); }   // second look, after the claim word was seen published
+          if (eq) { atomicAdd (&L.cnt[2 * slot + strand], 1u); adv = true; }
+          else if (++probes >= AG4_S) { left = true; adv = true; }
+        }
+        else if (a == AG4_MARK) { left = true; adv = true; }
+        else if (a == 0ull) {                           // the chain ends here: claim the slot, or MARK it if the table is closed
+          const bool closed = __hip_atomic_load (&L.n_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > AG4_CLOSE_AT;
+          const u64 old = atomicCAS ((unsigned long long *) &L.cw[slot], 0ull, closed ? AG4_MARK : (unsigned long long) (cw | AG4_PENDING));
+          if (old == 0ull) {
+            if (closed) left = true;
+            else {                                      // claimed: publish the k-mers, then the claim word
+              __hip_atomic_store ((unsigned long long *) &L.c0[slot], (unsigned long long) c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_store ((unsigned long long *) &L.c1[slot], (unsigned long long) c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              atomicAdd (&L.n_claimed, 1u);
+              __hip_atomic_store ((unsigned long long *) &L.cw[slot], (unsigned long long) cw, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+              atomicAdd (&L.cnt[2 * slot + strand], 1u);
+            }
+            adv = true;
+          }                                             // else somebody else took the slot: look at it again
+        }
+        else if (a != (cw | AG4_PENDING)) {             // another key (PENDING with our claim word: its owner is still writing, look again)
+          if (++probes >= AG4_S) { left = true; adv = true; }
+        }
+        if (left) {
+          const u32 o = atomicAdd (&L.n_ovf, 1u);
+          const u32 j = chunk_of_pos (BK, o), oc = chunk_id (j);
+          if (oc != TJ_NOCHUNK) {
+            u64 *q = dst + 4 * ((((u64) oc * TJ_CH0) << BK.ch_shift) + (o - ((j * TJ_CH0) << BK.ch_shift)));
+            q[0] = c0; q[1] = c1; q[2] = m2; q[3] = 0;
           }
         }
+        if (adv) { todo &= todo - 1u; probes = 0; }
       }
-      lds_barrier ();
     }
     __syncthreads ();
 
-    // emit this round's keys: filter, then one global atomic per workgroup
     u32 mine = 0;
-    u64 metas[AG_S / AG_BLOCK];
+    u64 metas[AG4_S / AG_BLOCK];
 #pragma unroll
-    for (int r = 0; r < AG_S / AG_BLOCK; r++) {
+    for (int r = 0; r < AG4_S / AG_BLOCK; r++) {
       const int slot = tid + r * AG_BLOCK;
       metas[r] = 0;
-      if (L.tag[slot]) {
-        const u32 cf = L.cf[slot], cr = L.cr[slot];
+      const u64 cw = L.cw[slot];
+      if (cw && cw != AG4_MARK) {
+        const u32 cf = L.cnt[2 * slot], cr = L.cnt[2 * slot + 1];
         const u64 flag = (cf ? 1ull : 0ull) | (cr ? 2ull : 0ull);
         const u64 cnt = ((u64) cf + (u64) cr) & 0xFFFFFull;           // 20-bit store wraps (reference :361)
         const int scnt = (cnt & 0x80000ull) ? (int) cnt - 0x100000 : (int) cnt;
-        const bool keep = remove_biased ? (flag == 3ull) : (scnt > 1);
-        if (keep) {
-          const u32 k2 = L.k2[slot];
+        if (remove_biased ? (flag == 3ull) : (scnt > 1)) {
+          const u32 k2 = (u32) (cw >> 1) & 0xFFFu;
           metas[r] = (u64) (k2 & 3u) | ((u64) (k2 >> 2) << TJ_META_LEN_SHIFT) | (cnt << TJ_META_COUNT_SHIFT) |
-                     (0xffeull << TJ_META_MISM_SHIFT) | (flag << TJ_META_FLAG_SHIFT) | (1ull << 63);   // bit 63: marker, cleared on store
+                     (0xffeull << TJ_META_MISM_SHIFT) | (flag << TJ_META_FLAG_SHIFT);
           mine++;
         }
       }
     }
-    u32 x = mine;                                       // exclusive scan over the workgroup
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up (x, o); if (lane >= o) x += y; }
+    const u32 x = wave_inclusive_scan (mine);
     if (lane == 63) L.wsum[wave] = x;
     __syncthreads ();
     u32 wbase = 0, total = 0;
-    for (int wv = 0; wv < AG_BLOCK / 64; wv++) { const u32 s = L.wsum[wv]; if (wv < wave) wbase += s; total += s; }
+    for (int wv = 0; wv < AG_BLOCK / 64; wv++) { const u32 sm = L.wsum[wv]; if (wv < wave) wbase += sm; total += sm; }
     if (tid == 0) L.total = total ? atomicAdd (&fin->n_kept, total) : 0u;
     __syncthreads ();
     u64 at = (u64) L.total + wbase + x - mine;
 #pragma unroll
-    for (int r = 0; r < AG_S / AG_BLOCK; r++)
+    for (int r = 0; r < AG4_S / AG_BLOCK; r++)
       if (metas[r]) {
         const int slot = tid + r * AG_BLOCK;
-        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = L.k0[slot]; q[1] = L.k1[slot]; q[2] = metas[r] & ~(1ull << 63); }
+        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = L.c0[slot]; q[1] = L.c1[slot]; q[2] = metas[r]; }
         else fin->overflow = 1u;
         at++;
       }
     __threadfence_block ();
     __syncthreads ();
-    n = L.n_ovf;                                        // leftovers now sit at the front of the bucket
+    n = L.n_ovf;
+    { const u64 *t = src; src = dst; dst = (u64 *) t; }
     __syncthreads ();
   }
 }
@@ -2981,14 +2994,14 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
 
   // steps 1-2: per-bucket hash aggregation + filter (reference :351-374)
   rc = ensure (c->kept, (size_t) kept_cap * 24, c->stream);
-  if (!rc && c->W <= 2) rc = ensure (c->ovf, c->pool.cap, c->stream);   // second pool for the aggregation's leftover rounds
+  if (!rc) rc = ensure (c->ovf, c->pool.cap, c->stream);   // second pool for the aggregation's leftover rounds
   if (rc) return rc;
   HIPCHK (hipEventRecord (c->ev_f0, c->stream));
   const Buckets BK = make_buckets (c);
   switch (c->W) {
     case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
     case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
-    default: hipLaunchKernelGGL (aggregate_kernel<4>, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
+    default: hipLaunchKernelGGL (aggregate4_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
   }
   HIPCHK (hipGetLastError ());
   // counters, bucket sizes and the aggregation's own counts, in one copy; then the buckets are emptied (the aggregation

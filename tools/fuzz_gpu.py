@@ -49,7 +49,7 @@ def random_stream():
 
 while time.time() < t_end:
     it += 1
-    k = rng.choice([2, 3, 5, 8, 10, 12, 13, 15, 20, 25, 28, 29, 31, 32])
+    k = rng.choice([int(x) for x in os.environ["FUZZ_K"].split(",")] if os.environ.get("FUZZ_K") else [2, 3, 5, 8, 10, 12, 13, 15, 20, 25, 28, 29, 31, 32])
     m = rng.choice([1, 2, 3, 4, 6])
     rb = rng.choice([0, 1])
     mc = rng.choice([0, 1, 3, 5, 50])
