@@ -880,13 +880,10 @@ struct StageSink
   {
     if (bound + round_max > (u32) S) { partition (); bound = 0; }
     bound += round_max;
-    const u64 mask = __ballot (have);
-    if (!mask) return;
-    const int lane = threadIdx.x & 63, leader = __ffsll ((long long) mask) - 1;
-    u32 at = 0;
-    if (lane == leader) at = atomicAdd (&L.n, (u32) __popcll (mask));
-    at = __shfl (at, leader) + (u32) __popcll (mask & ((1ull << lane) - 1ull));
     if (have) {
+      // (a uniform-address atomic under a divergent condition: the compiler's atomic optimiser makes it one LDS atomic
+      // per wavefront plus a lane prefix -- and does it better than the hand-written ballot / shuffle version did)
+      const u32 at = atomicAdd (&L.n, 1u);
       u64 w[W];
       pack_raw<W> (c0, c1, base, len10, flag, k, w);
 #pragma unroll
