@@ -511,11 +511,13 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
       // one LDS atomic per wavefront (512 same-address atomics serialise): exclusive prefix of the lane counts
       const u32 n = (u32) __popc (cand);
       const u32 incl = wave_inclusive_scan (n);
+      const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, 63);     // (a uniform operand keeps the compiler's atomic optimiser from looping over lanes)
       u32 wbase = 0;
-      if ((tid & 63) == 63 && incl) wbase = atomicAdd (&T.ncand, incl);
+      if ((tid & 63) == 63 && total) wbase = atomicAdd (&T.ncand, total);
       wbase = (u32) __builtin_amdgcn_readlane ((int) wbase, 63);
       u32 at = wbase + incl - n;
-      while (cand) { int b = __ffs ((int) cand) - 1; cand &= cand - 1u; if (at < (u32) G::MAXCAND) T.cand[at] = (unsigned short) (p0 + b); at++; }
+      // (never more than MAXCAND in a tile: a candidate takes m' >= 2 positions -- one in the monomer mode, where MAXCAND = TILE)
+      while (cand) { int b = __ffs ((int) cand) - 1; cand &= cand - 1u; T.cand[at] = (unsigned short) (p0 + b); at++; }
     }
     STAMP (4);
     lds_barrier ();
