@@ -354,10 +354,24 @@ __device__ __forceinline__ void emit_record (bool have, u64 c0, u64 c1, u64 meta
 // streams).
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
+
+// The LDS-DMA instruction itself, from inline assembly.  Through the builtin the compiler knows that a VMEM operation
+// writes LDS and, unable to tell where, waits for it (s_waitcnt vmcnt(0): the prefetch AND every bucket store in
+// flight) in front of LDS accesses all over phases 2 and 3 -- the prefetch was complete a few hundred cycles after its
+// issue instead of a tile later.  Unknown to the compiler, it is waited for exactly once, by the explicit s_waitcnt in
+// front of phase 1's reads of the landing zone.  (Hidden VMEM operations can only make the compiler's own vmcnt waits
+// longer, never shorter: the counter returns in issue order.)  lds_wave_base must be wave-uniform.
+__device__ __forceinline__ void lds_dma16 (const void *gptr, void *lds_wave_base)
+{
+  const u32 m0v = (u32) __builtin_amdgcn_readfirstlane ((int) (u32) (size_t) (lptr_t) lds_wave_base);
+  u32 saved;                                            // (M0 is the compiler's: put it back)
+  asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(saved) : "v"(gptr), "s"(m0v) : "memory");
+}
 __device__ __forceinline__ void issue_chunk (const uint8_t *__restrict__ seq, long n_bytes, long g, uint4 *lds_wave_base)
 {
   const bool inside = (g >= 0) && (g + 16 <= n_bytes);
-  __builtin_amdgcn_global_load_lds ((gptr_t) (inside ? seq + g : seq), (lptr_t) lds_wave_base, 16, 0, 0);
+  lds_dma16 (inside ? seq + g : seq, lds_wave_base);
 }
 
 // the same chunk, byte by byte, for chunks that are not entirely inside the stream (first and last tile only)
@@ -476,8 +490,8 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
           for (int i = 0; i < G::NLOAD; i++) {
             const int c = tid + i * BLOCK;
             if (c < G::NCHUNK) {
-              __builtin_amdgcn_global_load_lds ((gptr_t) (pl + 16l * i * BLOCK), (lptr_t) &raw[c - (tid & 63)], 16, 0, 0);
-              if ((tid & 63) == 0) __builtin_amdgcn_global_load_lds ((gptr_t) (pl + 16l * i * BLOCK - 16), (lptr_t) &raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)], 16, 0, 0);
+              lds_dma16 (pl + 16l * i * BLOCK, &raw[c - (tid & 63)]);
+              if ((tid & 63) == 0) lds_dma16 (pl + 16l * i * BLOCK - 16, &raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)]);
             }
           }
         }
