@@ -1280,9 +1280,7 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
         }
       }
     }
-    u32 x = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up (x, o); if (lane >= o) x += y; }
+    const u32 x = wave_inclusive_scan (mine);
     if (lane == 63) L.wsum[wave] = x;
     __syncthreads ();
     u32 wbase = 0, total = 0;
