@@ -35,16 +35,19 @@ typedef struct hopo_counter_struct *hopo_counter;
 /* reference: src/hopo_counter.h:20-32 (passed and stored BY VALUE; 64 bytes on LP64) */
 typedef struct
 {
-  char *reference_fasta_filename, *outdir;
-  bool paired_end, remove_biased, save_vcf;
-  gff3_t gff;
-  int max_distance_per_flank,
-      kmer_size,
-      min_tract_size,
-      levenshtein_distance,
-      min_coverage,
-      n_samples,
-      n_threads;
+  char *reference_fasta_filename;   /* not used on this path (BWA index of the reference genome) */
+  char *outdir;                     /* not used on this path */
+  bool paired_end;                  /* R2 is appended to R1's counter by the caller (src/genome_set.c:72-73) */
+  bool remove_biased;               /* keep a (context, length) only if it was seen on both strands (canon_flag == 3) */
+  bool save_vcf;                    /* not used on this path */
+  gff3_t gff;                       /* stored and handed back, never dereferenced here */
+  int max_distance_per_flank;       /* not used on this path (context grouping) */
+  int kmer_size;                    /* flanking context length k, 2..32 */
+  int min_tract_size;               /* shortest tract recorded (1 behaves as 2) */
+  int levenshtein_distance;         /* not used on this path */
+  int min_coverage;                 /* a context is indexed only if its depth reaches this */
+  int n_samples;
+  int n_threads;
 } tatajuba_options_t;
 
 /* reference: src/hopo_counter.h:34-49 (40 bytes).  The bitfield word is laid out LSB-first by gcc/clang on x86-64:
@@ -52,28 +55,34 @@ typedef struct
  * The device kernels build exactly this 64-bit word (see TJ_META_* in tatajuba_amd.h). */
 typedef struct
 {
-  uint64_t context[2];  /* left / right flanking k-mers, 2 bits per base, first base in the two lowest bits */
-  int64_t base:2,       /* 0 = A/T tract, 1 = C/G tract (canonical strand) */
-          length:10,    /* tract length in bases (signed 10-bit store: 512 wraps to -512) */
-          count:20,     /* depth of this (context, base, length) */
-          mismatches:12,
-          multi:3,
-          neg_strand:2,
-          canon_flag:3; /* 1 = seen as A/C run, 2 = seen as T/G run (reverse-complemented), 3 = both */
-  int32_t read_offset,  /* start of left flank within the read; -1 once finalised (reference: src/hopo_counter.c:511) */
-          loc_ref_id,
-          loc_pos,
-          loc_last;
+  uint64_t context[2];    /* left / right flanking k-mers, 2 bits per base, first base in the two lowest bits */
+  int64_t base:2;         /* 0 = A/T tract, 1 = C/G tract (canonical strand) */
+  int64_t length:10;      /* tract length in bases (signed 10-bit store: 512 wraps to -512) */
+  int64_t count:20;       /* depth of this (context, base, length) */
+  int64_t mismatches:12;
+  int64_t multi:3;
+  int64_t neg_strand:2;
+  int64_t canon_flag:3;   /* 1 = seen as A/C run, 2 = seen as T/G run (reverse-complemented), 3 = both */
+  int32_t read_offset;    /* start of left flank within the read; -1 once finalised (reference: src/hopo_counter.c:511) */
+  int32_t loc_ref_id;
+  int32_t loc_pos;
+  int32_t loc_last;
 } hopo_element;
 
 /* reference: src/hopo_counter.h:51-59 (136 bytes on LP64) */
 struct hopo_counter_struct
 {
-  hopo_element *elem;
-  char *name;
-  int ref_start, n_elem, n_alloc, kmer_size, coverage;
-  int *idx_initial, *idx_final, n_idx;
-  tatajuba_options_t opt;
+  hopo_element *elem;       /* raw records (only those added through update_hopo_counter_from_seq) until finalised, then the histogram */
+  char *name;               /* copy of the first file's name */
+  int ref_start;
+  int n_elem;               /* raw tracts so far; after finalise: entries of the histogram */
+  int n_alloc;
+  int kmer_size;
+  int coverage;             /* estimate_coverage_hopo_counter's value (src/hopo_counter.c:419-438) */
+  int *idx_initial;         /* per indexed context: first entry in elem ... */
+  int *idx_final;           /* ... and one past its last */
+  int n_idx;
+  tatajuba_options_t opt;   /* by value, as given to the first new_or_append call */
   int ref_counter;
 };
 
