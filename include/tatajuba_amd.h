@@ -76,6 +76,16 @@ void *tjamd_host_alloc (size_t bytes);
 void tjamd_host_free (void *p);
 int  tjamd_sync (tjamd_counter *c);
 
+/* Hint: reads of about stream_bytes in total are coming.  Allocates the raw-record storage for them in one piece (up to
+ * 4 GB) instead of by repeated growth. */
+int  tjamd_reserve (tjamd_counter *c, size_t stream_bytes, int min_tract_size);
+
+/* A mark is a point in the counter's stream: tjamd_mark() returns a small handle (>= 0; < 0 on error), tjamd_wait_mark()
+ * returns once everything queued before the mark has finished -- without waiting for what was queued after it (how the
+ * feeder re-uses a pinned batch buffer while later batches are in flight).  Eight marks are live at a time. */
+int  tjamd_mark (tjamd_counter *c);
+int  tjamd_wait_mark (tjamd_counter *c, int mark);
+
 long tjamd_raw_count (tjamd_counter *c);          /* synchronises; number of raw records so far; <0 on error */
 long tjamd_download_raw (tjamd_counter *c, tjamd_record *out, long capacity); /* unordered multiset */
 long tjamd_undefined_runs (tjamd_counter *c);     /* qualifying non-ACGTU runs with no earlier tract in the read (dropped) */

@@ -79,7 +79,7 @@ EXPORTS = [
     "dna_in_2_bits", "bit_2_dna",
     "tjamd_device_count", "tjamd_last_error", "tjamd_version", "tjamd_counter_create", "tjamd_counter_destroy",
     "tjamd_counter_reset", "tjamd_counter_set_stream", "tjamd_counter_device", "tjamd_scan_device", "tjamd_scan_host",
-    "tjamd_scan_host_located", "tjamd_read_file_stream_mt", "tjamd_host_alloc", "tjamd_host_free", "tjamd_sync", "tjamd_raw_count",
+    "tjamd_scan_host_located", "tjamd_read_file_stream_mt", "tjamd_host_alloc", "tjamd_host_free", "tjamd_sync", "tjamd_mark", "tjamd_wait_mark", "tjamd_reserve", "tjamd_raw_count",
     "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_kept_count",
     "tjamd_n_idx", "tjamd_coverage", "tjamd_download_kept", "tjamd_download_idx", "tjamd_kept_device_ptr",
     "tjamd_merge_samples", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches",

@@ -130,6 +130,8 @@ tjf_parse_file (const char *path, int n_threads, size_t window_bytes, const tjf_
   tjf_job job[TJF_MAX_THREADS];
   pthread_t th[TJF_MAX_THREADS];
   int started[TJF_MAX_THREADS];
+  long set_mark[2] = {-1, -1};
+  long n_windows = 0;
 
   const int trace = getenv ("TATAJUBA_AMD_FEEDER_TRACE") != NULL;
   double t0 = tjf_now (), t_alloc = 0, t_parse = 0, t_put = 0, t_sync = 0, tt;
@@ -166,7 +168,14 @@ tjf_parse_file (const char *path, int n_threads, size_t window_bytes, const tjf_
     }
     starts[nj] = wend;
     tt = tjf_now ();
-    if (sink->sync && sink->sync (sink->ctx)) { done = 1; total_reads = -3; break; }   /* this buffer set was sent two windows ago */
+    /* this buffer set was sent two windows ago: with marks only ITS batches are waited for (the window sent last is
+     * still in flight); every fourth window a full synchronisation lets the sink refresh what it knows (exact counts) */
+    if (sink->mark && sink->wait) {
+      if (set_mark[set] >= 0 && sink->wait (sink->ctx, set_mark[set])) { done = 1; total_reads = -3; break; }
+      if ((n_windows & 3) == 3 && sink->sync && sink->sync (sink->ctx)) { done = 1; total_reads = -3; break; }
+    }
+    else if (sink->sync && sink->sync (sink->ctx)) { done = 1; total_reads = -3; break; }
+    n_windows++;
     t_sync += tjf_now () - tt; tt = tjf_now ();
     for (i = 0; i < nj; i++) {
       job[i].data = data; job[i].n = n; job[i].start = starts[i]; job[i].stop = starts[i + 1]; job[i].is_last = (i == nj - 1);
@@ -189,6 +198,7 @@ tjf_parse_file (const char *path, int n_threads, size_t window_bytes, const tjf_
       if (job[i].out_len && sink->put (sink->ctx, job[i].out, job[i].out_len, job[i].n_reads)) { done = 1; total_reads = -3; break; }
       total_reads += job[i].n_reads;
     }
+    if (total_reads >= 0 && sink->mark) { set_mark[set] = sink->mark (sink->ctx); if (set_mark[set] < 0) total_reads = -3; }
     t_put += tjf_now () - tt;
     if (total_reads < 0) break;
     if (done) break;

@@ -12,6 +12,8 @@ typedef struct
   void (*release) (void *ctx, void *p);
   int (*put) (void *ctx, const unsigned char *stream, size_t n_bytes, long n_reads);  /* reads + '\n' each, in file order; != 0 aborts */
   int (*sync) (void *ctx);                                  /* may be NULL; everything put so far has been consumed */
+  long (*mark) (void *ctx);                                 /* may be NULL (then sync is used): a point after everything put so far */
+  int (*wait) (void *ctx, long mark);                       /* everything put before that mark has been consumed */
 } tjf_sink;
 
 /* 1 = not gzip (first two bytes are not 1f 8b), 0 = gzip, -1 = cannot open */

@@ -2380,6 +2380,8 @@ struct tjamd_counter
   bool bins_zeroed = false;
   long n_kept = 0; int n_idx = 0, coverage = 0, status = -1;
   hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_f0 = nullptr, ev_f1 = nullptr;
+  hipEvent_t marks[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // tjamd_mark / tjamd_wait_mark
+  unsigned mark_seq = 0;
   bool scan_timed = false, fin_timed = false;
   long last_scan_launches = 0;
   unsigned scan_seq = 0;
@@ -2449,6 +2451,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
                    &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx, &c->ovf};
   for (DevBuf *b : all) release (*b);
+  for (hipEvent_t ev : c->marks) if (ev) (void) hipEventDestroy (ev);
   if (c->d_state) (void) hipFree (c->d_state);
   if (c->d_lctr) (void) hipFree (c->d_lctr);
   if (c->h_state) (void) hipHostFree (c->h_state);
@@ -2522,6 +2525,27 @@ extern "C" int tjamd_sync (tjamd_counter *c)
   return TJAMD_OK;
 }
 
+// A mark is a point in the counter's stream (everything queued before it); waiting for a mark does not wait for what was
+// queued after it.  The feeder uses marks to re-use a pinned batch buffer as soon as ITS copy and scan are done while
+// later batches are still in flight.  Eight marks are live at a time (the ninth re-uses the first one's slot).
+extern "C" int tjamd_mark (tjamd_counter *c)
+{
+  if (!c) return -set_err (TJAMD_ERR_ARG, "null counter");
+  if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
+  const int slot = (int) (c->mark_seq++ & 7u);
+  if (!c->marks[slot] && hipEventCreateWithFlags (&c->marks[slot], hipEventDisableTiming) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipEventCreate failed");
+  if (hipEventRecord (c->marks[slot], c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipEventRecord failed");
+  return slot;
+}
+
+extern "C" int tjamd_wait_mark (tjamd_counter *c, int mark)
+{
+  if (!c || mark < 0 || mark > 7 || !c->marks[mark]) return set_err (TJAMD_ERR_ARG, "bad mark");
+  HIPCHK (hipSetDevice (c->device));
+  HIPCHK (hipEventSynchronize (c->marks[mark]));
+  return TJAMD_OK;
+}
+
 // stream synchronisation + exact counts
 static int queue_counter_copies (tjamd_counter *c)
 {
@@ -2557,25 +2581,18 @@ static int sync_counters (tjamd_counter *c)
 }
 
 // room for `add` more raw records (an upper bound), wherever the hash sends them, written by `grid` workgroups
-static int ensure_buckets (tjamd_counter *c, u64 add, int grid)
+static void choose_chunk_size (tjamd_counter *c, u64 records)
+{ // fixed by the first scan (or reservation) after a reset: at most ~16 k chunks for this many records
+  if (c->ch_shift >= 0) return;
+  const u64 units = records / (16384ull * TJ_CH0);
+  int sft = 2;                                          // a chunk holds more than one partition pass stages (4096 records)
+  while ((1ull << sft) < units) sft++;
+  c->ch_shift = sft;
+}
+
+// chunk table with rows of at least need_maxj entries (rows keep their contents)
+static int ensure_table (tjamd_counter *c, u64 need_maxj)
 {
-  if (c->ch_shift < 0) {                                // chunk size: at most ~16 k chunks for this many records
-    const u64 units = add / (16384ull * TJ_CH0);
-    int sft = 2;                                        // a chunk holds more than one partition pass stages (4096 records)
-    while ((1ull << sft) < units) sft++;
-    c->ch_shift = sft;
-  }
-  const u64 ch = (u64) TJ_CH0 << c->ch_shift;
-  const u64 pad_bucket = 0;                             // (no padding records any more)
-  (void) grid;
-  // one chunk per bucket is always claimed ahead of the cursor
-  const u64 need_chunks = c->chunk_bound + (add + ch - 1) / ch + 2 * TJ_P;
-  c->buckets_clean = false;
-  const u64 need_maxj = (c->bucket_bound + add + ch - 1) / ch + 3;      // worst case: everything in one bucket
-  if (need_chunks >= TJ_NOCHUNK || need_maxj >= (1ull << 31)) return set_err (TJAMD_ERR_CAPACITY, "batch too large for the chunk table");
-  int rc = ensure (c->pool, (size_t) need_chunks * ch * c->W * 8, c->stream, std::min<size_t> ((size_t) (c->chunk_bound * ch * c->W * 8), c->pool.cap));
-  if (rc) return rc;
-  c->pool_chunks = (u32) std::min<u64> (c->pool.cap / (ch * c->W * 8), TJ_NOCHUNK - 1);
   if (need_maxj > c->maxj) {
     const u32 nmaxj = (u32) std::max<u64> (need_maxj, (u64) c->maxj + c->maxj / 2);
     void *np = nullptr;
@@ -2596,6 +2613,25 @@ static int ensure_buckets (tjamd_counter *c, u64 add, int grid)
     }
     c->table.p = np; c->table.cap = (size_t) TJ_P * nmaxj * 4; c->maxj = nmaxj;
   }
+  return TJAMD_OK;
+}
+
+static int ensure_buckets (tjamd_counter *c, u64 add, int grid)
+{
+  choose_chunk_size (c, add);
+  const u64 ch = (u64) TJ_CH0 << c->ch_shift;
+  const u64 pad_bucket = 0;                             // (no padding records any more)
+  (void) grid;
+  // one chunk per bucket is always claimed ahead of the cursor
+  const u64 need_chunks = c->chunk_bound + (add + ch - 1) / ch + 2 * TJ_P;
+  c->buckets_clean = false;
+  const u64 need_maxj = (c->bucket_bound + add + ch - 1) / ch + 3;      // worst case: everything in one bucket
+  if (need_chunks >= TJ_NOCHUNK || need_maxj >= (1ull << 31)) return set_err (TJAMD_ERR_CAPACITY, "batch too large for the chunk table");
+  int rc = ensure (c->pool, (size_t) need_chunks * ch * c->W * 8, c->stream, std::min<size_t> ((size_t) (c->chunk_bound * ch * c->W * 8), c->pool.cap));
+  if (rc) return rc;
+  c->pool_chunks = (u32) std::min<u64> (c->pool.cap / (ch * c->W * 8), TJ_NOCHUNK - 1);
+  rc = ensure_table (c, need_maxj);
+  if (rc) return rc;
   c->chunk_bound = need_chunks;
   c->bucket_bound += add + pad_bucket;
   return TJAMD_OK;
@@ -2608,6 +2644,24 @@ static int check_scan_args (tjamd_counter *c, int min_tract_size)
   if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
   if (min_tract_size < 1 || min_tract_size > 32) return set_err (TJAMD_ERR_ARG, "min_tract_size %d outside [1,32] (reference clamp: src/main.c:186-187)", min_tract_size);
   return TJAMD_OK;
+}
+
+// Room for the raw records of about stream_bytes of reads, allocated in one piece instead of by repeated growth (each
+// growth is an allocation, a device copy and a synchronisation).  A hint: scans allocate what they need anyway.
+extern "C" int tjamd_reserve (tjamd_counter *c, size_t stream_bytes, int min_tract_size)
+{
+  int rc = check_scan_args (c, min_tract_size);
+  if (rc) return rc;
+  HIPCHK (hipSetDevice (c->device));
+  const u64 records = std::min<u64> ((u64) (stream_bytes / (size_t) std::max (min_tract_size, 2) + 1), ((u64) 4 << 30) / ((u64) c->W * 8));   // (a hint is not worth more than 4 GB)
+  choose_chunk_size (c, records);
+  const u64 ch = (u64) TJ_CH0 << c->ch_shift;
+  const size_t keep = std::min<size_t> (c->pool.cap, (size_t) (c->chunk_bound * ch * c->W * 8));
+  rc = ensure (c->pool, (size_t) ((records / ch + 2 * TJ_P + 1) * ch * c->W * 8), c->stream, keep);
+  if (rc) return rc;
+  c->pool_chunks = (u32) std::min<u64> (c->pool.cap / (ch * c->W * 8), TJ_NOCHUNK - 1);
+  c->buckets_clean = c->buckets_clean && c->table.p != nullptr;
+  return ensure_table (c, (c->bucket_bound + records + ch - 1) / ch + 3);
 }
 
 // one launch of the scan over [d_stream, d_stream + n_bytes) (16-byte aligned, starts and ends on read boundaries)

@@ -169,6 +169,8 @@ static int tj_sink_put (void *ctx, const unsigned char *stream, size_t n_bytes, 
 /* (tjamd_raw_count rather than tjamd_sync: it also brings the exact record counts back, so the device storage is sized
  * for what the batches really produced, not for the sum of their worst cases) */
 static int tj_sink_sync (void *ctx) { return tjamd_raw_count (((tj_gpu_sink *) ctx)->dev) < 0; }
+static long tj_sink_mark (void *ctx) { return tjamd_mark (((tj_gpu_sink *) ctx)->dev); }
+static int tj_sink_wait (void *ctx, long mark) { return tjamd_wait_mark (((tj_gpu_sink *) ctx)->dev, (int) mark); }
 
 static int
 tj_feeder_threads (void)
@@ -214,6 +216,8 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
       long got;
       g.dev = tj_device_counter (h); g.min_tract_size = opt.min_tract_size;
       sk.ctx = &g; sk.alloc = tj_sink_alloc; sk.release = tj_sink_release; sk.put = tj_sink_put; sk.sync = tj_sink_sync;
+      sk.mark = tj_sink_mark; sk.wait = tj_sink_wait;
+      (void) tjamd_reserve (g.dev, (size_t) st.st_size / 2, opt.min_tract_size);   /* about half of a FASTQ file is sequence */
       got = tjf_parse_file (filename, threads, (size_t) TJ_FEEDER_WINDOW, &sk);
       if (got == -2 || got == -3) tj_fatal ("%s", got == -2 ? "out of pinned host memory for the feeder" : tjamd_last_error ());
       if (got >= 0) {
@@ -293,7 +297,7 @@ long
 tjamd_read_file_stream_mt (const char *path, unsigned char *out, long capacity, long *n_reads, int n_threads, long window_bytes)
 {
   tj_mem_sink m = {out, capacity, 0, 0};
-  tjf_sink sk = {&m, tj_mem_alloc, tj_mem_release, tj_mem_put, NULL};
+  tjf_sink sk = {&m, tj_mem_alloc, tj_mem_release, tj_mem_put, NULL, NULL, NULL};
   long got;
   if (tjf_is_plain_file (path) != 1) return tjamd_read_file_stream (path, out, capacity, n_reads);
   got = tjf_parse_file (path, n_threads, (size_t) (window_bytes > 0 ? window_bytes : TJ_FEEDER_WINDOW), &sk);
