@@ -153,7 +153,7 @@ __device__ __forceinline__ void classify_word_fast (u32 x, u32 prev_word, u32 &c
   const u32 c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
   code8 = __builtin_amdgcn_udot4 (c, 0x40100401u, 0u, false);
   // delimiter: the only byte of the fast path without bit 6
-  const u32 s = (~x >> 6) & 0x01010101u;
+  const u32 s = ~(x >> 6) & 0x01010101u;                 // (shift first: the and-not is then one instruction)
   sent4 = __builtin_amdgcn_udot4 (s, 0x08040201u, 0u, false);
   // validation: every byte must be the letter its code stands for, or '\n' where bit 6 is clear -- one 8-entry byte
   // table look-up (v_perm_b32): entries 0..3 = 'A','C','G','T' by code, entries 4..7 = '\n'
