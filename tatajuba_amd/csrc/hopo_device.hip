@@ -147,21 +147,24 @@ __device__ __forceinline__ void classify_word (u32 x, u32 prev_byte, u32 &code8,
 // Fast path of classify_word for the bytes that make up almost all of a read stream: upper-case A C G T and the read
 // delimiter.  Same code / start / delimiter planes (the code of a delimiter byte is never used); `bad` comes back non-zero if some byte is anything else (then the
 // caller redoes the chunk with classify_word, which also produces the non-ACGTU plane).
-__device__ __forceinline__ void classify_word_fast (u32 x, u32 prev_word, u32 &code8, u32 &start4, u32 &sent4, u32 &bad)
+// `hi` selects the weights 16..128 and the results are added to the incoming start4 / sent4: two words give one byte of
+// each plane through the dot product's accumulator, without a merge instruction.
+__device__ __forceinline__ void classify_word_fast (u32 x, u32 prev_word, bool hi, u32 &code8, u32 &start4, u32 &sent4, u32 &bad)
 {
+  const u32 wts = hi ? 0x80402010u : 0x08040201u;
   // 2-bit codes, packed with one dot product (byte j * 4^j)
   const u32 c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
   code8 = __builtin_amdgcn_udot4 (c, 0x40100401u, 0u, false);
   // delimiter: the only byte of the fast path without bit 6
   const u32 s = ~(x >> 6) & 0x01010101u;                 // (shift first: the and-not is then one instruction)
-  sent4 = __builtin_amdgcn_udot4 (s, 0x08040201u, 0u, false);
+  sent4 = __builtin_amdgcn_udot4 (s, wts, sent4, false);
   // validation: every byte must be the letter its code stands for, or '\n' where bit 6 is clear -- one 8-entry byte
   // table look-up (v_perm_b32): entries 0..3 = 'A','C','G','T' by code, entries 4..7 = '\n'
   bad = x ^ __builtin_amdgcn_perm (0x0A0A0A0Au, 0x54474341u, c | (s << 2));
   // run start: byte differs from its predecessor
   const u32 d = x ^ __builtin_amdgcn_alignbit (x, prev_word, 24);
   const u32 nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) >> 7) & 0x01010101u;
-  start4 = __builtin_amdgcn_udot4 (nz, 0x08040201u, 0u, false);
+  start4 = __builtin_amdgcn_udot4 (nz, wts, start4, false);
 }
 
 // ---- diagnostic build only (-DTJ_STAMPS=1): where does a tile's time go?  Never enabled in the product library. ----
@@ -454,11 +457,12 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
         }
         const u32 prev0 = prevw >> 24;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          u32 c8, s4, e4, b;
-          classify_word_fast (w[j], prevw, c8, s4, e4, b);
-          code32 |= c8 << (8 * j); st16 |= s4 << (4 * j); se16 |= e4 << (4 * j); bad |= b;
-          prevw = w[j];
+        for (int j = 0; j < 4; j += 2) {                // two words per byte of the start / delimiter planes
+          u32 c8a, c8b, s8 = 0, e8 = 0, ba, bb;
+          classify_word_fast (w[j], prevw, false, c8a, s8, e8, ba);
+          classify_word_fast (w[j + 1], w[j], true, c8b, s8, e8, bb);
+          code32 |= (c8a | (c8b << 8)) << (16 * (j / 2)); st16 |= s8 << (4 * j); se16 |= e8 << (4 * j); bad |= ba | bb;
+          prevw = w[j + 1];
         }
         if (__builtin_expect (bad != 0u, 0)) {          // lower case, U, N, anything else: exact classification
           T.odd[tpar] = 1u;
