@@ -163,7 +163,8 @@ __device__ __forceinline__ void classify_word_fast (u32 x, u32 prev_word, bool h
   bad = x ^ __builtin_amdgcn_perm (0x0A0A0A0Au, 0x54474341u, c | (s << 2));
   // run start: byte differs from its predecessor
   const u32 d = x ^ __builtin_amdgcn_alignbit (x, prev_word, 24);
-  const u32 nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) >> 7) & 0x01010101u;
+  // (the flag stays in bit 7 of its byte: the sum comes out 128 times too large and the caller's merge shift absorbs it)
+  const u32 nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
   start4 = __builtin_amdgcn_udot4 (nz, wts, start4, false);
 }
 
@@ -461,7 +462,9 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
           u32 c8a, c8b, s8 = 0, e8 = 0, ba, bb;
           classify_word_fast (w[j], prevw, false, c8a, s8, e8, ba);
           classify_word_fast (w[j + 1], w[j], true, c8b, s8, e8, bb);
-          code32 |= (c8a | (c8b << 8)) << (16 * (j / 2)); st16 |= s8 << (4 * j); se16 |= e8 << (4 * j); bad |= ba | bb;
+          code32 |= (c8a | (c8b << 8)) << (16 * (j / 2));
+          st16 |= j ? s8 << 1 : s8 >> 7;                // (s8 = 128 x the byte of 8 flags)
+          se16 |= e8 << (4 * j); bad |= ba | bb;
           prevw = w[j + 1];
         }
         if (__builtin_expect (bad != 0u, 0)) {          // lower case, U, N, anything else: exact classification
