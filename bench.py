@@ -191,11 +191,12 @@ def main():
     dominant = "scan" if scan_avg >= fin_avg else "finalise"
     # HBM bytes per launch from the PMC passes of the same command (tools/pmc_traffic.py -> profiles/; rocprofv3 cannot
     # run inside the timed process), only when they were taken on this workload
-    traffic = {}
+    traffic, traffic_rw = {}, {}
     try:
         tj_prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
         if args.reads == 10_000_000 and L == 150 and k == 10 and m == 3:
             traffic = {kk: vv["hbm_bytes"] for kk, vv in tj_prof.items() if isinstance(vv, dict)}
+            traffic_rw = {kk: (vv["hbm_read_bytes"], vv["hbm_write_bytes"]) for kk, vv in tj_prof.items() if isinstance(vv, dict)}
     except (OSError, ValueError, KeyError):
         pass
     roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None}
@@ -203,6 +204,8 @@ def main():
         roof.update({"kernel": "scan_bins_kernel<1>" if k <= 12 else ("scan_bins_kernel<2>" if k <= 28 else "scan_bins_kernel<4>"),
                      "achieved": scan_gbs, "frac": scan_gbs / HBM_PEAK_GBS, "ms": scan_avg, "algorithmic_bytes": scan_bytes,
                      "traffic": traffic.get("scan_bins_kernel<1>") if k <= 12 else None})
+        if k <= 12 and "scan_bins_kernel<1>" in traffic_rw:   # reads = the stream (no re-reads); writes = the raw records leaving the kernel
+            roof["traffic_read"], roof["traffic_write"] = traffic_rw["scan_bins_kernel<1>"]
     else:
         roof.update({"kernel": "finalise (aggregate_kernel dominates)", "achieved": fin_gbs, "frac": fin_gbs / HBM_PEAK_GBS,
                      "ms": fin_avg, "algorithmic_bytes": fin_bytes})
