@@ -248,9 +248,10 @@ __device__ __forceinline__ u32 bits32 (const u32 *a, int bitpos)
 // reverse complement of a k-mer of at most 16 bases held in 32 bits
 __device__ __forceinline__ u32 revcomp_k32 (u32 x, int k)
 {
-  u32 y = __brev (~x);
-  y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
-  return y >> (32 - 2 * k);
+  const u32 y = __brev (~x);
+  u32 z;                                                // pair swap = bit-field insert of y >> 1 (even bits) into y << 1; the
+  asm ("v_bfi_b32 %0, %1, %2, %3" : "=v"(z) : "s"(0x55555555u), "v"(y >> 1), "v"(y << 1));   // compiler spends 5 instructions on it
+  return z >> (32 - 2 * k);
 }
 
 __device__ __forceinline__ u64 kmask (int k) { return (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1ull); }
