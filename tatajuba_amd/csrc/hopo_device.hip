@@ -259,9 +259,12 @@ __device__ __forceinline__ u64 kmask (int k) { return (k >= 32) ? ~0ull : ((1ull
 // reverse complement of a k-mer packed first-base-lowest (reference: src/hopo_counter.c:241-242 builds it base by base)
 __device__ __forceinline__ u64 revcomp_k (u64 x, int k)
 {
-  u64 y = __brevll (~x);
-  y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
-  return y >> (64 - 2 * k);
+  const u64 y = __brevll (~x);
+  const u32 lo = (u32) y, hi = (u32) (y >> 32);
+  u32 zl, zh;                                           // the pair swap never crosses the 32-bit halves: one v_bfi_b32 each
+  asm ("v_bfi_b32 %0, %1, %2, %3" : "=v"(zl) : "s"(0x55555555u), "v"(lo >> 1), "v"(lo << 1));
+  asm ("v_bfi_b32 %0, %1, %2, %3" : "=v"(zh) : "s"(0x55555555u), "v"(hi >> 1), "v"(hi << 1));
+  return (((u64) zh << 32) | zl) >> (64 - 2 * k);
 }
 
 __device__ __forceinline__ u32 stream_byte (const uint8_t *seq, long n, long p)
