@@ -100,7 +100,9 @@ struct DevCounters
   u32 pad[2];
   // per-launch counters, double-buffered: launch i works on lc[i & 1] and zeroes lc[(i + 1) & 1] for the next launch
   // (no memset between launches)
-  struct { u64 n_fix; u32 work, pad; } lc[2];
+  // work = tile counter of the main scan kernel of the launch; n_slow = tiles the fast kernel handed to the generic one
+  // (stream edges, bytes outside ACGT\n, too many candidates); work_slow = the generic kernel's counter over that list
+  struct { u64 n_fix; u32 work, n_slow, work_slow, pad[3]; } lc[2];
 };
 
 #ifndef TJ_TILE_GROUP
@@ -397,32 +399,50 @@ __device__ __noinline__ EdgeChunk edge_chunk (const uint8_t *__restrict__ seq, l
 // by the lane that owns chunk c.  It must be a __shared__ variable of its own: the compiler orders every later LDS access
 // that MAY alias an in-flight LDS-DMA behind vmcnt(0), and members of one struct all may alias -- as part of TileLds the
 // "prefetch" was waited for at the first LDS instruction after its issue.
+// Where the tiles of a launch come from.  list == nullptr: the stream cut into n_tiles pieces of TILE bytes, handed out in
+// groups of TJ_TILE_GROUP.  Otherwise: the tiles the fast kernel (scan_fast_kernel) left to this one -- tile t of that
+// kernel owns the tract starts in [t * fown, (t + 1) * fown); each is covered here by NSUB = ceil (fown / TILE) pieces,
+// handed out two at a time (the list is short, or the stream is slow-path material anyway).
+struct TileSrc { const u32 *list; long fown; };
+
 template <int BLOCK, int TILE, int CANDDIV, class Sink>
 __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
-                                            TileLds<BLOCK, TILE, CANDDIV> &T, uint4 *raw, Sink &sink, DevCounters *ctr, FixEntry *fix, u32 fix_cap, int par)
+                                            TileLds<BLOCK, TILE, CANDDIV> &T, uint4 *raw, Sink &sink, DevCounters *ctr, FixEntry *fix, u32 fix_cap, int par,
+                                            const TileSrc src = TileSrc {nullptr, 0})
 {
   typedef TileLds<BLOCK, TILE, CANDDIV> G;
   const int tid = threadIdx.x;
   const u64 km = kmask (k);
   const u64 kbits = (1ull << k) - 1ull;                 // k <= 32
+  const bool listed = src.list != nullptr;
+  const u32 nsub = listed ? (u32) ((src.fown + TILE - 1) / TILE) : 1u;
+  // (a group is reserved while its predecessor's first tile is worked on and looked up during the predecessor's last
+  // tile: with at least two tiles per group a workgroup barrier lies between the two)
+  const u32 tgroup = listed ? 2u : (u32) TJ_TILE_GROUP;
+  u32 *const work = listed ? &ctr->lc[par].work_slow : &ctr->lc[par].work;
+  if (listed) n_tiles = (long) ctr->lc[par].n_slow * (long) nsub;
+  // first stream byte a work item owns, and how many (multiples of 16)
+  auto own_start = [&] (long w) -> long { return listed ? (long) src.list[(u32) w / nsub] * src.fown + (long) ((u32) w % nsub) * TILE : w * (long) TILE; };
+  auto own_len = [&] (long w) -> int { return listed ? (int) min ((long) TILE, src.fown - (long) ((u32) w % nsub) * TILE) : TILE; };
 
   // Tiles are handed out dynamically in groups of TJ_TILE_GROUP (one global atomic per group): workgroups differ in
   // how many tracts their tiles hold, and a static split leaves the slow ones running alone at the end.
   if (tid == 0) {
-    T.odd[0] = 0; T.odd[1] = 0; T.grp[0] = atomicAdd (&ctr->lc[par].work, (u32) TJ_TILE_GROUP);
-    if (blockIdx.x == 0) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; }
+    T.odd[0] = 0; T.odd[1] = 0; T.grp[0] = atomicAdd (work, tgroup);
+    if (blockIdx.x == 0 && !listed) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; }
   }
   lds_barrier ();
   long tile = (long) T.grp[0];
-  long grp_end = tile + TJ_TILE_GROUP;
+  long grp_end = tile + tgroup;
   u32 gpar = 0, it = 0;
   if (tile < n_tiles) {
+    const long w0 = own_start (tile) - TJ_HL;
 #pragma unroll
     for (int i = 0; i < G::NLOAD; i++) {
       const int c = tid + i * BLOCK;
       if (c < G::NCHUNK) {
-        issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * c, &raw[c - (tid & 63)]);
-        if ((tid & 63) == 0) issue_chunk (seq, n_bytes, tile * (long) TILE - TJ_HL + 16l * (c - 1), &raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)]);
+        issue_chunk (seq, n_bytes, w0 + 16l * c, &raw[c - (tid & 63)]);
+        if ((tid & 63) == 0) issue_chunk (seq, n_bytes, w0 + 16l * (c - 1), &raw[G::NCHUNK + (tid >> 6) + i * (BLOCK / 64)]);
       }
     }
   }
@@ -430,8 +450,9 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
   STAMP_DECL;
   while (tile < n_tiles) {
     STAMP (0);
-    if (tid == 0 && tile + TJ_TILE_GROUP == grp_end) T.grp[gpar ^ 1u] = atomicAdd (&ctr->lc[par].work, (u32) TJ_TILE_GROUP);  // first tile of a group: reserve the next
-    const long g0 = tile * (long) TILE - TJ_HL;         // stream position of window byte 0 (may be negative)
+    if (tid == 0 && tile + tgroup == grp_end) T.grp[gpar ^ 1u] = atomicAdd (work, tgroup);  // first tile of a group: reserve the next
+    const long g0 = own_start (tile) - TJ_HL;           // stream position of window byte 0 (may be negative)
+    const int olen = own_len (tile);                    // tract starts in window positions [TJ_HL, TJ_HL + olen) belong to this tile
 
     // ---- phase 1: classify the prefetched chunks into LDS, then prefetch the next tile ------------------------
     const u32 tpar = it & 1u;
@@ -494,7 +515,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     const long nt = (tile + 1 < grp_end) ? tile + 1 : (long) T.grp[gpar ^ 1u];
     {
       if (nt < n_tiles) {
-        const long ng0 = nt * (long) TILE - TJ_HL;
+        const long ng0 = own_start (nt) - TJ_HL;
         if (ng0 >= 16 && ng0 + (long) G::WIN <= n_bytes) {      // (uniform) the whole window and the chunk in front are inside: no per-lane checks
           const uint8_t *pl = seq + ng0 + 16l * tid;
 #pragma unroll
@@ -522,7 +543,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     lds_barrier ();
     STAMP (3);
 #if defined(TJ_EXP_STOP_AFTER) && TJ_EXP_STOP_AFTER == 1       // experiment builds only (tools/exp_scan_pmc.sh)
-    { if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + TJ_TILE_GROUP; } tile = nt; it++; continue; }
+    { if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + tgroup; } tile = nt; it++; continue; }
 #endif
 
     // ---- phase 2: candidate tract starts among this lane's 16 positions ------------------------------------
@@ -533,6 +554,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
       if (mprime <= 0) cand &= (u32) (S >> 1);                      // monomer mode: the next position starts a run too
       for (int j = 1; j < mprime; j++) cand &= ~(u32) (S >> j);     // next m'-1 positions continue the run
       cand &= ~(u32) reinterpret_cast<unsigned short *> (T.sent)[p0 >> 4];  // a run of delimiters is not a tract
+      if (16 * tid >= olen) cand = 0;                               // (a listed tile may own less than TILE positions)
       // one LDS atomic per wavefront (512 same-address atomics serialise): exclusive prefix of the lane counts
       const u32 n = (u32) __popc (cand);
       const u32 incl = wave_inclusive_scan (n);
@@ -548,7 +570,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     lds_barrier ();
     STAMP (5);
 #if defined(TJ_EXP_STOP_AFTER) && TJ_EXP_STOP_AFTER == 2
-    { if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + TJ_TILE_GROUP; } tile = nt; it++; continue; }
+    { if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + tgroup; } tile = nt; it++; continue; }
 #endif
 
     // ---- phase 3: one lane per candidate --------------------------------------------------------------------
@@ -642,7 +664,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
     }
     lds_barrier ();
     STAMP (8);
-    if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + TJ_TILE_GROUP; }
+    if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + tgroup; }
     tile = nt;
     it++;
   }
@@ -892,6 +914,9 @@ struct StageSink
   u32 bound;                                            // upper bound of the records staged (workgroup-uniform)
   u32 cur_j, cur_chunk;                                 // owner thread (tid < TJ_P): the chunk its bucket is being written to
   STAMP_MEMBER
+#if defined(TJ_EXP_SINK)
+  u32 exp_prev = 0;
+#endif
 
   __device__ __forceinline__ void start ()
   {
@@ -924,6 +949,12 @@ struct StageSink
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     lds_barrier ();                                     // every append so far is in LDS
+#if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 1            // experiment builds only: records dropped
+    if (tid == 0) L.n = 0;
+    lds_barrier ();
+    return;
+#endif
+    PSTAMP (9);
     const u32 n = L.n;
     if (tid < TJ_P) L.hist[tid] = 0;
     lds_barrier ();
@@ -942,6 +973,7 @@ struct StageSink
       }
     }
     lds_barrier ();
+    PSTAMP (10);
     u32 cnt = 0, incl = 0;
     if (tid < TJ_P) {                                   // exclusive prefix of the bucket counts (waves 0..3)
       cnt = L.hist[tid];
@@ -956,9 +988,14 @@ struct StageSink
       L.offs[tid] = wbase + incl - cnt;
       // reserve the bucket's run: the global atomic's round trip runs under the LDS permutation below (its result is
       // first looked at after that)
+#if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 2             // timing experiment: the reservation of the pass before (no wait for this one)
+      p0 = exp_prev; if (cnt) exp_prev = atomicAdd (&B.cursors[tid], cnt);
+#else
       if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
+#endif
     }
     lds_barrier ();
+    PSTAMP (11);
 #pragma unroll
     for (int r = 0; r < R; r++)                          // in-place permutation into bucket order (records are in registers)
       if (bb[r] != TJ_EMPTY) {
@@ -967,6 +1004,7 @@ struct StageSink
         for (int j = 0; j < WS; j++) L.rec[d * WS + j] = w[r][j];
         L.bin[d] = (unsigned char) bb[r];
       }
+    PSTAMP (12);
     if (tid < TJ_P && cnt) {                            // where the reserved run lives
       const u32 ch = (u32) TJ_CH0 << B.ch_shift;
       bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
@@ -982,14 +1020,20 @@ struct StageSink
       }
       L.split[tid] = sp; L.gbase2[tid] = g2;
     }
+    PSTAMP (13);
     lds_barrier ();
+    PSTAMP (14);
 #pragma unroll
     for (int r = 0; r < R; r++) {                       // sorted slot i -> its place in the bucket's run (coalesced per run)
       const u32 i = (u32) tid + (u32) r * BLOCK;
       if (i < n) {
         const u32 b = L.bin[i], o = i - L.offs[b], sp = L.split[b];
         const u64 g = (o < sp) ? L.gbase[b] : L.gbase2[b];
+#if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 3
+        if (g == 0x123456789ull) {
+#else
         if (g != ~0ull) {
+#endif
           u64 *q = B.pool + (g + (o < sp ? o : o - sp)) * W;
 #pragma unroll
           for (int j = 0; j < WS; j++) q[j] = L.rec[i * WS + j];
@@ -998,6 +1042,7 @@ struct StageSink
       }
     }
     lds_barrier ();                                     // the staging buffer is free again
+    PSTAMP (15);
   }
 
   __device__ __forceinline__ void finish () { partition (); }
@@ -1012,14 +1057,296 @@ struct StageSink
 template <int W>
 __global__ __launch_bounds__ (TJ_SB_BLOCK, 6)
 void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
-                       Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap, int par)
+                       Buckets BK, DevCounters *ctr, FixEntry *fix, u32 fix_cap, int par, TileSrc src)
 {
   __shared__ TileLds<TJ_SB_BLOCK, TJ_SB_TILE> T;
   __shared__ uint4 raw[TileLds<TJ_SB_BLOCK, TJ_SB_TILE>::NRAW];
   __shared__ StageLds<W> SL;
   StageSink<W, TJ_SB_BLOCK> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
   sink.start ();
-  scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE, 2> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap, par);
+  scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE, 2> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap, par, src);
+  sink.finish ();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast scan for the streams that make up almost all input: tiles whose bytes are all upper-case A C G T or the read
+// delimiter.  Same results as scan_tiles (reference: src/hopo_counter.c:219-258,285-307); any tile it cannot vouch for --
+// a window that touches the stream's ends, a byte outside the five, more candidates than its list holds -- goes on a
+// list that scan_bins_kernel works through afterwards (TileSrc), so nothing here has to know about lower case, U, N,
+// the stale-context rule or stream edges.
+//
+// What makes it fast is the instruction mix.  On gfx950 a wave-wide and / or / xor / add / sub / right shift / mov /
+// v_bitop3 whose operands are VGPRs, inline constants or (VOP1/VOP2) literals issues every 2 cycles; everything else --
+// any SGPR operand, left shifts, v_perm, v_dot4, v_alignbit, DPP, v_lshl_or, v_ffbl, compares -- takes 4
+// (tools/ubench/valu_rate3.hip).  So masks live in VGPRs, boolean algebra goes through v_bitop3, and the 4-cycle
+// instructions are kept for what only they can do (byte table look-ups, bit gathers, funnel shifts).
+//
+// Geometry: 512 lanes x 32 bytes = a 16 KiB window per tile; the first 32 bytes (>= max k) and the last 64 are halo, the
+// 16288 between them are the tract starts the tile owns (a tract whose end + k leaves the window walks the stream in
+// global memory, like scan_tiles does).  A byte is one of the five iff the table look-up on its low three bits (all
+// different: A 1, '\n' 2, C 3, T 4, G 7) gives the byte back; those three bits are then all that run detection needs
+// (equal bytes <=> equal low bits), and code / letter / run-start bits are gathered with one v_dot4 per word each.
+// Each lane keeps the run-start and letter masks of its 32 positions in registers and finds its candidates from them
+// (plus one DPP move for the next lane's bits); the rest is scan_tiles' phase 3 with 32-bit windows: one funnel read of
+// the run-start plane for the run end, one of the letter plane for "k letters on both sides" (whenever 2k + length <= 32),
+// one of the code plane per flank.
+
+#define FK_BLOCK    512
+#define FK_UNIT     32                  // stream bytes per lane
+#define FK_WIN      (FK_BLOCK * FK_UNIT)
+#define FK_HL       32
+#define FK_HR       64
+#define FK_OWN      (FK_WIN - FK_HL - FK_HR)
+#define FK_MAXCAND  1024
+#define FK_GROUP    8                   // tiles per work-counter atomic
+
+struct FastLds
+{
+  u32 code[FK_WIN / 16 + 4];            // 2-bit codes, 16 positions per word (+ zeroed pad for funnel reads)
+  u32 st[FK_WIN / 32 + 4];              // run starts (byte differs from its predecessor)
+  u32 lt[FK_WIN / 32 + 4];              // letters (not a read delimiter)
+  unsigned short cand[FK_MAXCAND];
+  u32 ncand[4];                         // per tile, three in rotation (zeroed two tiles ahead)
+  u32 bad[4];                           // per tile, likewise: some byte outside ACGT\n
+  u32 grp[2];
+};
+
+// v_bitop3_b32 truth tables: bit (a << 2 | b << 1 | c) of the immediate = f (a, b, c)
+#define BITOP3_XOR_AND   0x48           // (a ^ c) & b
+#define BITOP3_OR_XOR    0xF6           // a | (b ^ c)
+
+template <int W>
+__global__ __launch_bounds__ (FK_BLOCK, 6)
+void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_ftiles, int k, int mprime,
+                       Buckets BK, DevCounters *ctr, u32 *__restrict__ slow_list, int par, int all_slow)
+{
+  __shared__ FastLds T;
+  __shared__ uint4 raw[FK_WIN / 16];
+  __shared__ StageLds<W> SL;
+  StageSink<W, FK_BLOCK> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
+  sink.start ();
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);
+  // masks in VGPRs (an SGPR or literal operand would halve the issue rate of the instructions that use them)
+  u32 M07, M06, M40;
+  asm ("v_mov_b32 %0, 0x07070707" : "=v"(M07));
+  asm ("v_mov_b32 %0, 0x06060606" : "=v"(M06));
+  asm ("v_mov_b32 %0, 0x40404040" : "=v"(M40));
+  const u32 kb32 = (1u << k) - 1u, km32 = (k >= 16) ? 0xFFFFFFFFu : (1u << (2 * k)) - 1u;
+  const u32 own = (tid == 0 || tid >= (FK_WIN - FK_HR) / FK_UNIT) ? 0u : 0xFFFFFFFFu;   // halo lanes own no tract start
+
+  if (tid == 0) {
+    T.grp[0] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP);
+    if (blockIdx.x == 0) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; }
+  }
+  if (tid < 4) { T.ncand[tid] = 0; T.bad[tid] = 0; T.code[FK_WIN / 16 + tid] = 0; T.st[FK_WIN / 32 + tid] = 0; T.lt[FK_WIN / 32 + tid] = 0; }
+  lds_barrier ();
+  long tile = (long) T.grp[0];
+  long grp_end = tile + FK_GROUP;
+  u32 gpar = 0, it = 0;
+
+  // a tile is done here iff its whole window, and the four bytes in front of it, lie inside the stream
+  auto interior = [&] (long t) { const long g = t * (long) FK_OWN - FK_HL; return !all_slow && g >= 16 && g + (long) FK_WIN <= n_bytes; };
+  // next tile's bytes: HBM -> LDS, 2 KiB per wave (two instructions of 1 KiB), and the word in front of the wave's
+  // first byte through the scalar cache
+  u32 pred = 0;
+  auto prefetch = [&] (long t) {
+    const uint8_t *g = seq + (t * (long) FK_OWN - FK_HL) + 2048l * wave;
+    lds_dma16 (g + 16l * lane, &raw[128 * wave]);
+    lds_dma16 (g + 1024l + 16l * lane, &raw[128 * wave + 64]);
+    pred = *reinterpret_cast<const u32 *> (g - 4);
+  };
+  if (tile < n_ftiles && interior (tile)) prefetch (tile);
+
+  STAMP_DECL;
+  while (tile < n_ftiles) {
+    STAMP (0);
+    if (tid == 0 && tile + FK_GROUP == grp_end) T.grp[gpar ^ 1u] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP);
+    const u32 slot = it % 3u, slot2 = (it + 2u) % 3u;
+    if (tid == 0) { T.ncand[slot2] = 0; T.bad[slot2] = 0; }
+    const bool inside = interior (tile);
+    u32 S32 = 0, L32 = 0;
+    const u32 pred_now = pred;
+    if (inside) {
+      // ---- phase 1: 32 bytes per lane -> codes, run starts, letters -------------------------------------------
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has landed in raw
+      STAMP (1);
+      const uint4 va = raw[2 * tid], vb = raw[2 * tid + 1];
+      const u32 x[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+      // the word in front: the last word of the lane before (one DPP move); the wave's first lane has it from `pred`
+      const u32 prevw = (u32) __builtin_amdgcn_update_dpp ((int) pred_now, (int) x[7], 0x138, 0xF, 0xF, false);   // wave_shr:1
+      u32 selp = prevw & M07, bad = 0, r[8], sc[4] = {0, 0, 0, 0}, lc[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const u32 w = x[j];
+        const u32 sel = w & M07;
+        // every byte must be the table's entry for its low three bits: 1 'A', 2 '\n', 3 'C', 4 'T', 7 'G' (entries 0, 5, 6
+        // hold bytes with other low bits: they can never match)
+        const u32 rec = __builtin_amdgcn_perm (0x47000054u, 0x430A4101u, sel);
+        bad = __builtin_amdgcn_bitop3_b32 (bad, w, rec, BITOP3_OR_XOR);
+        // 2-bit code = bits 1-2 of b ^ (b >> 1) (A 0, C 1, G 2, T 3), gathered 4 bytes -> 8 bits (twice the value: the codes sit at bit 1)
+        const u32 cd = __builtin_amdgcn_bitop3_b32 (w, M06, w >> 1, BITOP3_XOR_AND);
+        r[j] = __builtin_amdgcn_udot4 (cd, 0x40100401u, 0u, false);
+        // letters have bit 6 ('\n' has not): 64 x the byte of 8 flags per pair of words
+        const u32 wts = (j & 1) ? 0x80402010u : 0x08040201u;
+        lc[j >> 1] = __builtin_amdgcn_udot4 (w & M40, wts, lc[j >> 1], false);
+        // run start: low three bits differ from the byte before
+        const u32 d = sel ^ __builtin_amdgcn_alignbit (sel, selp, 24);
+        const u32 nz = __builtin_amdgcn_perm (0x01010101u, 0x01010100u, d);       // byte != 0 -> 1
+        sc[j >> 1] = __builtin_amdgcn_udot4 (nz, wts, sc[j >> 1], false);
+        selp = sel;
+      }
+      const u32 code_lo = (r[0] >> 1) | (r[1] << 7) | (r[2] << 15) | (r[3] << 23);
+      const u32 code_hi = (r[4] >> 1) | (r[5] << 7) | (r[6] << 15) | (r[7] << 23);
+      S32 = sc[0] | (sc[1] << 8) | (sc[2] << 16) | (sc[3] << 24);
+      L32 = ((lc[0] | (lc[1] << 8)) >> 6) | (((lc[2] | (lc[3] << 8)) >> 6) << 16);
+      *reinterpret_cast<uint2 *> (&T.code[2 * tid]) = make_uint2 (code_lo, code_hi);
+      T.st[tid] = S32;
+      T.lt[tid] = L32;
+      if (bad) T.bad[slot] = 1u;
+    }
+    STAMP (2);
+    // the tile after this one
+    const long nt = (tile + 1 < grp_end) ? tile + 1 : (long) T.grp[gpar ^ 1u];
+    if (inside) asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw has been read: it may be refilled
+    if (nt < n_ftiles && interior (nt)) prefetch (nt);
+    STAMP (3);
+
+#if defined(FK_EXP_STOP) && FK_EXP_STOP == 1          // experiment builds only (tools/exp_fast_phases.sh)
+    if (S32 == 0x12345u && L32 == 0x54321u) T.bad[3] = 1u;
+    S32 = 0;
+#endif
+    if (inside) {
+      // ---- phase 2: candidate tract starts among this lane's 32 positions ----------------------------------
+      // (the next lane's run starts come by DPP; the wave's last lane assumes none, i.e. that runs go on: phase 3
+      // checks the length anyway)
+      const u32 nx = (u32) __builtin_amdgcn_update_dpp (0, (int) S32, 0x130, 0xF, 0xF, false);   // wave_shl:1
+      u32 cand = S32 & L32 & own;
+      for (int j = 1; j < mprime; j++) cand &= ~__builtin_amdgcn_alignbit (nx, S32, (u32) j);
+      const u32 n = (u32) __popc (cand);
+      const u32 incl = wave_inclusive_scan (n);
+      const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, 63);
+      u32 wbase = 0;
+      if (lane == 63 && total) wbase = atomicAdd (&T.ncand[slot], total);
+      wbase = (u32) __builtin_amdgcn_readlane ((int) wbase, 63);
+      u32 at = wbase + incl - n;
+      const u32 p0 = (u32) (FK_UNIT * tid);
+      while (cand) {
+        const u32 b = (u32) __ffs ((int) cand) - 1u;
+        cand &= cand - 1u;
+        if (at < FK_MAXCAND) T.cand[at] = (unsigned short) (p0 + b);
+        at++;
+      }
+    }
+    STAMP (4);
+    lds_barrier ();
+    STAMP (5);
+
+    // ---- phase 3: one lane per candidate ----------------------------------------------------------------------
+#if defined(FK_EXP_STOP) && FK_EXP_STOP <= 2
+    const u32 ncand_all = (T.ncand[slot] == 0x7FFFFFFFu) ? 1u : 0u;
+#else
+    const u32 ncand_all = T.ncand[slot];
+#endif
+    const bool give_up = !inside || T.bad[slot] != 0u || ncand_all > (u32) FK_MAXCAND;
+    if (give_up) {
+      if (tid == 0) slow_list[atomicAdd (&ctr->lc[par].n_slow, 1u)] = (u32) tile;
+    }
+    else {
+      const int ncand = (int) ncand_all;
+      const long g0 = tile * (long) FK_OWN - FK_HL;
+      for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
+        const int ci = cb0 + tid;
+        bool have = false;
+        u64 c0 = 0, c1 = 0, pos = 0;
+        u32 base = 0, flag = 0, len10 = 0;
+        if (ci < ncand) {
+          const int s = T.cand[ci];
+          // run end: first run start after s, looked for in the next 32 positions (bit 31 set: "not found" reads as a
+          // run of 32, which takes the general path below like every run that does not fit one 32-bit window)
+          const u32 ns32 = bits32 (T.st, s + 1) | 0x80000000u;
+          const int f = __ffs ((int) ns32) - 1;
+          const int need = f + 1 + 2 * k;
+          if (need <= 32) {
+            // k letters, the run, k letters: all inside one 32-bit window of the letter plane
+            const u32 lw = ~bits32 (T.lt, s - k);
+            const bool ok = ((lw << (32 - need)) == 0u) && (f + 1 >= mprime);
+            if (ok) {
+              const u32 lwin = bits32 (T.code, 2 * (s - k));
+              const u32 rwin = bits32 (T.code, 2 * (s + f + 1));
+              u32 l32 = lwin & km32, r32 = rwin & km32;
+              const u32 cb = (k < 16) ? ((lwin >> (2 * k)) & 3u) : ((T.code[s >> 4] >> (2 * (s & 15))) & 3u);
+              if (cb < 2u) { c0 = l32; c1 = r32; base = cb; flag = 1u; }
+              else { c0 = revcomp_k32 (r32, k); c1 = revcomp_k32 (l32, k); base = 3u - cb; flag = 2u; }
+              len10 = (u32) (f + 1);
+              pos = (u64) (g0 + s);
+              have = true;
+            }
+          }
+          else {
+            // general path: run end from 64-bit windows of the run-start plane, the two flanks checked separately
+            int e = -1;
+            {
+              const u64 ns = bits64 (T.st, s + 1);
+              if (ns) e = s + __ffsll ((long long) ns) - 1;
+              else for (int p = s + 65; p < FK_WIN; p += 64) {
+                const u64 n2 = bits64 (T.st, p);
+                if (n2) { e = p + __ffsll ((long long) n2) - 2; break; }
+              }
+            }
+            const long gs = g0 + s;
+            long len;
+            bool ok;
+            u32 l32 = 0, r32 = 0, cb = 0;
+            if (e >= 0 && e + k < FK_WIN) {             // everything needed is in LDS
+              len = e - s + 1;
+              ok = (((~bits32 (T.lt, s - k) | ~bits32 (T.lt, e + 1)) & kb32) == 0u) && (len >= mprime);
+              if (ok) {
+                l32 = bits32 (T.code, 2 * (s - k)) & km32; r32 = bits32 (T.code, 2 * (e + 1)) & km32;
+                cb = (T.code[s >> 4] >> (2 * (s & 15))) & 3u;
+              }
+            }
+            else {                                      // tract runs past the window: walk the stream (rare)
+              const u32 b = stream_byte (seq, n_bytes, gs);
+              long ge = gs;
+              while (stream_byte (seq, n_bytes, ge + 1) == b) ge++;
+              len = ge - gs + 1;
+              u64 left, right; u32 linv, rinv;
+              ok = flanks_from_stream (seq, n_bytes, gs, ge, k, left, right, linv, rinv) && (len >= mprime);
+              // (outside the window bytes may be anything: non-ACGTU flank bases pack as 0 in both orientations)
+              cb = byte_code (b);
+              if (ok) {
+                u64 cc0, cc1;
+                canonicalise (left, right, linv, rinv, cb, k, cc0, cc1, base, flag);
+                c0 = cc0; c1 = cc1; len10 = (u32) ((u64) len & 0x3FFull); pos = (u64) gs; have = true; ok = false;
+              }
+            }
+            if (ok) {
+              if (cb < 2u) { c0 = l32; c1 = r32; base = cb; flag = 1u; }
+              else { c0 = revcomp_k32 (r32, k); c1 = revcomp_k32 (l32, k); base = 3u - cb; flag = 2u; }
+              len10 = (u32) ((u64) len & 0x3FFull);
+              pos = (u64) gs;
+              have = true;
+            }
+          }
+        }
+        STAMP (6);
+#if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
+        if (have) asm volatile ("" :: "v"(c0), "v"(c1), "v"(base), "v"(len10), "v"(flag), "v"(pos));
+#else
+        sink.put (have, c0, c1, base, len10, flag, pos, (u32) min (ncand - cb0, FK_BLOCK));
+#endif
+        STAMP (7);
+      }
+    }
+    lds_barrier ();
+    STAMP (8);
+    if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + FK_GROUP; }
+    tile = nt;
+    it++;
+  }
+  STAMP_FLUSH;
   sink.finish ();
 }
 
@@ -2375,7 +2702,8 @@ struct tjamd_counter
   DevCounters *d_ctr = nullptr, *h_ctr = nullptr;     // scan counters (device / pinned host mirror)
   DevCounters *d_lctr = nullptr;                      // located-list counters
   u32 *d_cursors = nullptr, *h_cursors = nullptr;     // [TJ_P] records per bucket, then [TJ_P] = next free chunk
-  DevBuf pool, table, stage, fix, loc, prefix, rawlist;
+  DevBuf pool, table, stage, fix, loc, prefix, rawlist, slow;
+  int fast_mode = 1;          // 1: scan_fast_kernel + the generic kernel on what it leaves; 0: generic kernel only; 2: fast kernel leaves everything (tests)
   u32 pool_chunks = 0, maxj = 0;
   int ch_shift = -1;          // chunk = TJ_CH0 << ch_shift records; fixed by the first scan after a reset
   u64 bucket_bound = 0;       // upper bound of the fullest bucket (exact after a synchronisation)
@@ -2436,6 +2764,8 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   if (bm && atoi (bm) >= 1 && atoi (bm) <= BS_RANK_MAX) c->bin_rank_max = (u32) atoi (bm);
   const char *pc = getenv ("TATAJUBA_AMD_SCAN_PIECE");
   if (pc && atol (pc) >= 4096) c->piece_target = (size_t) atol (pc);
+  const char *fm = getenv ("TATAJUBA_AMD_FAST");          // test hook: 0 = generic scan kernel only, 2 = fast kernel hands every tile over
+  if (fm && atoi (fm) >= 0 && atoi (fm) <= 2) c->fast_mode = atoi (fm);
   const char *sl = getenv ("TATAJUBA_AMD_BUCKET_SLACK");
   if (sl && atof (sl) >= 1.0) c->slack = atof (sl);
   HIPCHK_NULL (hipStreamCreateWithFlags (&c->own_stream, hipStreamNonBlocking));
@@ -2459,7 +2789,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   if (!c) return;
   (void) hipSetDevice (c->device);
   (void) hipStreamSynchronize (c->stream);
-  DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
+  DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->slow, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
                    &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx, &c->ovf};
   for (DevBuf *b : all) release (*b);
   for (hipEvent_t ev : c->marks) if (ev) (void) hipEventDestroy (ev);
@@ -2693,23 +3023,37 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
   rc = ensure_buckets (c, bound, grid + 1);             // + the fix-up kernel's block-per-record inserts
   c->raw_bound += (u64) (n_bytes / (size_t) mprime) + 1u;
   if (!rc) rc = ensure (c->fix, (size_t) TJ_FIX_CAP * sizeof (FixEntry), c->stream);
+  // fast kernel: tiles of FK_OWN tract starts, two workgroups resident per CU; the list of the tiles it leaves to the generic
+  // kernel (every one of them at worst), which that kernel covers with ceil (FK_OWN / TJ_SB_TILE) of its own tiles each
+  const long n_ftiles = (long) ((n_bytes + FK_OWN - 1) / FK_OWN);
+  const int fgrid = (int) std::min<long> (n_ftiles, (long) c->n_cu * 3);
+  const int lgrid = (int) std::min<long> (n_ftiles * ((FK_OWN + TJ_SB_TILE - 1) / TJ_SB_TILE), (long) c->n_cu * TJ_SB_WG_PER_CU);
+  if (!rc && c->W == 1 && c->fast_mode) rc = ensure (c->slow, (size_t) n_ftiles * 4 + 64, c->stream);
   if (rc) return rc;
   const uint8_t *seq = (const uint8_t *) d_stream;
   const Buckets BK = make_buckets (c);
   FixEntry *fix = (FixEntry *) c->fix.p;
   const int par = (int) (c->scan_seq++ & 1u);            // per-launch counters are double-buffered (DevCounters::lc)
   if (first) HIPCHK (hipEventRecord (c->ev_s0, c->stream));
+  const TileSrc plain = {nullptr, 0};
   switch (c->W) {
     case 1:
-      hipLaunchKernelGGL (scan_bins_kernel<1>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par);
+      if (c->fast_mode) {
+        // the fast kernel takes every tile it can vouch for and lists the others; the generic kernel then works through the list
+        hipLaunchKernelGGL (scan_fast_kernel<1>, dim3 (fgrid), dim3 (FK_BLOCK), 0, c->stream, seq, (long) n_bytes, n_ftiles, c->k, mprime, BK, c->d_ctr,
+                            (u32 *) c->slow.p, par, c->fast_mode == 2 ? 1 : 0);
+        const TileSrc listed = {(const u32 *) c->slow.p, (long) FK_OWN};
+        hipLaunchKernelGGL (scan_bins_kernel<1>, dim3 (lgrid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, 0l, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, listed);
+      }
+      else hipLaunchKernelGGL (scan_bins_kernel<1>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, plain);
       hipLaunchKernelGGL (nrun_fixup_bins_kernel<1>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par);
       break;
     case 2:
-      hipLaunchKernelGGL (scan_bins_kernel<2>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par);
+      hipLaunchKernelGGL (scan_bins_kernel<2>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, plain);
       hipLaunchKernelGGL (nrun_fixup_bins_kernel<2>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par);
       break;
     default:
-      hipLaunchKernelGGL (scan_bins_kernel<4>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par);
+      hipLaunchKernelGGL (scan_bins_kernel<4>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, plain);
       hipLaunchKernelGGL (nrun_fixup_bins_kernel<4>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par);
       break;
   }

@@ -1,6 +1,6 @@
-"""Diagnostic only: per-phase time shares of the scan kernel from in-kernel s_memtime stamps.
+"""Diagnostic only: where a workgroup of the scan kernel spends its time, from in-kernel s_memtime stamps of thread 0.
 Needs tatajuba_amd/libtatajuba_amd_diag.so (hopo_device.hip built with -DTJ_STAMPS=1; see tools/build_diag.sh).
-The stamped build's run time is not a benchmark number (its stamps serialise the phases); read the shares."""
+The stamped build's run time is not a benchmark number; read the shares."""
 import ctypes as C
 import os
 import sys
@@ -28,12 +28,10 @@ for it in range(3):
     c.sync()
     L.tjamd_debug_stamps(out, 1)
 v = np.array(list(out), dtype=np.float64)
-names = ["loop-top", "classify", "prefetch-issue", "barrierA", "phase2", "barrierB", "phase3-compute", "put",
-         "barrier-end"]
+names = ["0 loop-top", "1 wait-dma", "2 phase1", "3 prefetch-issue", "4 phase2", "5 barrierA", "6 phase3-compute", "7 put (incl. partition)",
+         "8 barrier-end", "9 part:entry-barrier", "10 part:hist+rank", "11 part:scan+reserve", "12 part:permute", "13 part:owners", "14 part:barrier",
+         "15 part:copy-out"]
 print("stamped scan ms", c.last_scan_ms())
 tot = v[:9].sum()
-for n, x in zip(names, v[:9]):
-    print(f"{n:16s} {x / tot * 100:6.2f} %")
-pn = ["put:insert", "put:barrier1", "put:owners(take_block)", "put:barrier2", "put:copy", "put:barrier3"]
-for n, x in zip(pn, v[9:15]):
-    print(f"   {n:24s} {x / tot * 100:6.2f} %   (inside put)")
+for n, x in zip(names, v[:16]):
+    print(f"{n:28s} {x / tot * 100:6.2f} %")
