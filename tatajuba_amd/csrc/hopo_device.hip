@@ -738,15 +738,24 @@ __global__ void nrun_fixup_list_kernel (const uint8_t *__restrict__ seq, long n_
 
 // ---- compact raw records and their hash ---------------------------------------------------------------------------
 // Between the scan and the aggregation a raw tract is W 64-bit words, W chosen from k so that nothing is wasted:
-//   W = 1 (k <= 12): flag | len << 2 | ctx1 << 12 | ctx0 << (12 + 2k) | base << (12 + 4k)          (<= 61 bits)
+//   W = 1 (k <= 12): low half  = ctx1 | len[7:0] << 24
+//                    high half = ctx0 | len[9:8] << 24 | base << 26 | flag << 27      (fields at fixed places: packing is
+//                    two shift-or instructions on 32-bit halves whatever k is; the word without its flag is the reduction key)
 //   W = 2 (k <= 28): { 1 | base << 1 | len[4:0] << 2 | ctx0 << 7 ,  ctx1 | len[9:5] << 56 | flag << 61 }
 //                    (word 0 is never 0 and never uses bit 63: the aggregation claims table slots with it)
 //   W = 4          : { ctx0, ctx1, base | len << 2 | flag << 12, 0 }   (k > 28; padded so that 4 records fill a 128-byte line)
 // flag == 3 never occurs in a raw record (one tract, one strand): it marks a padding ("null") record.
 
 template <int W> __device__ __forceinline__ void pack_raw (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w);
+#define R1_FLAG_SHIFT 59                // W = 1 record: strand flag in bits 59-60 (27-28 of the high half)
+#define R1_KEY_MASK   (~(3ull << R1_FLAG_SHIFT))
+__device__ __forceinline__ u64 pack_rec1 (u32 c0, u32 c1, u32 base, u32 len10, u32 flag)
+{
+  const u32 lo = c1 | (len10 << 24), hi = c0 | ((len10 >> 8) << 24) | (base << 26) | (flag << 27);
+  return ((u64) hi << 32) | lo;
+}
 template <> __device__ __forceinline__ void pack_raw<1> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
-{ w[0] = (u64) flag | ((u64) len10 << 2) | (c1 << 12) | (c0 << (12 + 2 * k)) | ((u64) base << (12 + 4 * k)); }
+{ w[0] = pack_rec1 ((u32) c0, (u32) c1, base, len10, flag); }
 template <> __device__ __forceinline__ void pack_raw<2> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
 { w[0] = 1ull | ((u64) base << 1) | ((u64) (len10 & 31u) << 2) | (c0 << 7); w[1] = c1 | ((u64) (len10 >> 5) << 56) | ((u64) flag << 61); }
 template <> __device__ __forceinline__ void pack_raw<4> (u64 c0, u64 c1, u32 base, u32 len10, u32 flag, int k, u64 *w)
@@ -756,8 +765,8 @@ template <int W> __device__ __forceinline__ void pack_null (u64 *w) { pack_raw<W
 template <int W> __device__ __forceinline__ void unpack_raw (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag);
 template <> __device__ __forceinline__ void unpack_raw<1> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
 {
-  const u64 x = w[0], km = kmask (k);
-  flag = (u32) (x & 3ull); len10 = (u32) ((x >> 2) & 0x3FFull); c1 = (x >> 12) & km; c0 = (x >> (12 + 2 * k)) & km; base = (u32) ((x >> (12 + 4 * k)) & 1ull);
+  const u32 lo = (u32) w[0], hi = (u32) (w[0] >> 32);
+  c1 = lo & 0xFFFFFFu; c0 = hi & 0xFFFFFFu; len10 = (lo >> 24) | (((hi >> 24) & 3u) << 8); base = (hi >> 26) & 1u; flag = (hi >> 27) & 3u;
 }
 template <> __device__ __forceinline__ void unpack_raw<2> (const u64 *w, int k, u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
 {
@@ -791,17 +800,17 @@ __device__ __forceinline__ u32 bucket_of_key (u64 c0, u64 c1, u32 base, u32 len1
   return (h ^ (h >> 8)) & 255u;
 }
 
-// the same for k-mers that fit 32 bits (identical value: dot products with a zero word leave the accumulator as it is)
-__device__ __forceinline__ u32 bucket_of_key32 (u32 c0, u32 c1, u32 base, u32 len10)
+// bucket of a one-word record (k <= 12), straight from its two halves (the strand flag is not part of the key)
+__device__ __forceinline__ u32 bucket_of_rec1 (u32 lo, u32 hi)
 {
-  u32 h = __builtin_amdgcn_udot4 (c0, 0x6D2B4F0Bu, base | (len10 << 2), false);
-  h = __builtin_amdgcn_udot4 (c1, 0xC5A34D17u, h, false);
+  u32 h = __builtin_amdgcn_udot4 (lo, 0x6D2B4F0Bu, 0u, false);
+  h = __builtin_amdgcn_udot4 (hi & 0x07FFFFFFu, 0xC5A34D17u, h, false);
   return (h ^ (h >> 8)) & 255u;
 }
 
 #define TJ_P        256                 // hash buckets
 #define TJ_PBITS    8
-#define TJ_STAGE_WORDS 2048             // 64-bit words of records a workgroup stages in LDS between partition passes
+#define TJ_STAGE_WORDS 4096             // 64-bit words of one-word records a workgroup stages in LDS between partition passes
 #define TJ_CH0      1536                // chunk size unit in records; chunks are TJ_CH0 << ch_shift with ch_shift >= 2
 #define TJ_EMPTY    0xFFFFFFFFu
 
@@ -868,7 +877,7 @@ __device__ __forceinline__ void bucket_insert_slow (u64 c0, u64 c1, u32 base, u3
 {
   u64 w[W];
   pack_raw<W> (c0, c1, base, len10, flag, k, w);
-  const u32 b = bucket_of_key (c0, c1, base, len10);
+  const u32 b = (W == 1) ? bucket_of_rec1 ((u32) w[0], (u32) (w[0] >> 32)) : bucket_of_key (c0, c1, base, len10);
   const u32 pos = atomicAdd (&B.cursors[b], 1u);
   bucket_claim_ahead (B, b, pos, 1u, ctr);
   const u64 at = bucket_slot (B, b, pos, true, ctr);
@@ -940,8 +949,19 @@ struct StageSink
       pack_raw<W> (c0, c1, base, len10, flag, k, w);
 #pragma unroll
       for (int j = 0; j < WS; j++) L.rec[at * WS + j] = w[j];
-      // (one-word records have k <= 12: the high halves of the k-mers are 0 and their two dot products add nothing)
-      L.bin[at] = (unsigned char) (W == 1 ? bucket_of_key32 ((u32) c0, (u32) c1, base, len10) : bucket_of_key (c0, c1, base, len10));
+      L.bin[at] = (unsigned char) (W == 1 ? bucket_of_rec1 ((u32) w[0], (u32) (w[0] >> 32)) : bucket_of_key (c0, c1, base, len10));
+    }
+  }
+
+  // a one-word record already packed (scan_fast_kernel); same contract as put
+  __device__ __forceinline__ void put1 (bool have, u32 lo, u32 hi, u32 round_max)
+  {
+    if (bound + round_max > (u32) S) { partition (); bound = 0; }
+    bound += round_max;
+    if (have) {
+      const u32 at = atomicAdd (&L.n, 1u);
+      L.rec[at] = ((u64) hi << 32) | lo;
+      L.bin[at] = (unsigned char) bucket_of_rec1 (lo, hi);
     }
   }
 
@@ -1092,12 +1112,13 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
 // one of the code plane per flank.
 
 #define FK_BLOCK    512
+#define FK_WG_PER_CU 2                  // 73 KB of LDS each (the 4096-record staging buffer is worth more than a third workgroup)
 #define FK_UNIT     32                  // stream bytes per lane
 #define FK_WIN      (FK_BLOCK * FK_UNIT)
 #define FK_HL       32
 #define FK_HR       64
 #define FK_OWN      (FK_WIN - FK_HL - FK_HR)
-#define FK_MAXCAND  1024
+#define FK_MAXCAND  4096                // (a tile with more candidates goes to the generic kernel: more than one per 4 positions)
 #define FK_GROUP    8                   // tiles per work-counter atomic
 
 struct FastLds
@@ -1105,7 +1126,7 @@ struct FastLds
   u32 code[FK_WIN / 16 + 4];            // 2-bit codes, 16 positions per word (+ zeroed pad for funnel reads)
   u32 st[FK_WIN / 32 + 4];              // run starts (byte differs from its predecessor)
   u32 lt[FK_WIN / 32 + 4];              // letters (not a read delimiter)
-  unsigned short cand[FK_MAXCAND];
+  unsigned short cand[FK_MAXCAND + 2];
   u32 ncand[4];                         // per tile, three in rotation (zeroed two tiles ahead)
   u32 bad[4];                           // per tile, likewise: some byte outside ACGT\n
   u32 grp[2];
@@ -1115,8 +1136,61 @@ struct FastLds
 #define BITOP3_XOR_AND   0x48           // (a ^ c) & b
 #define BITOP3_OR_XOR    0xF6           // a | (b ^ c)
 
+// reverse complement of a k-mer of at most 16 bases with the constants in VGPRs: bit reverse, then swap the two bits of
+// every base and complement in one v_bitop3 (rs = 32 - 2k)
+__device__ __forceinline__ u32 revcomp_v32 (u32 x, u32 m55, u32 rs)
+{
+  const u32 y = __brev (x);
+  // ~(((y >> 1) & 0x5555...) | ((y << 1) & 0xAAAA...)): a = y >> 1, b = y + y, c = mask -> ~(c ? a : b)
+  const u32 z = __builtin_amdgcn_bitop3_b32 (y >> 1, y + y, m55, 0x1B);
+  return z >> rs;
+}
+
+// A tract that does not fit the straight-line path of scan_fast_kernel's phase 3 (k + length + k > 32 positions): run end
+// from 64-bit windows of the run-start plane, flanks checked separately, and past the window's end a walk through the
+// stream in global memory -- scan_tiles' logic on this kernel's planes.  Returns false if the tract is not recorded.
+__device__ __noinline__ bool fast_general_tract (const FastLds &T, const uint8_t *__restrict__ seq, long n_bytes, long g0, int s, int k, int mprime,
+                                                 u32 &lo, u32 &hi)
+{
+  const u32 kb32 = (1u << k) - 1u, km32 = (k >= 16) ? 0xFFFFFFFFu : (1u << (2 * k)) - 1u;
+  int e = -1;
+  {
+    const u64 ns = bits64 (T.st, s + 1);
+    if (ns) e = s + __ffsll ((long long) ns) - 1;
+    else for (int p = s + 65; p < FK_WIN; p += 64) {
+      const u64 n2 = bits64 (T.st, p);
+      if (n2) { e = p + __ffsll ((long long) n2) - 2; break; }
+    }
+  }
+  const long gs = g0 + s;
+  long len;
+  u32 c0, c1, base, flag;
+  if (e >= 0 && e + k < FK_WIN) {                       // everything needed is in LDS
+    len = e - s + 1;
+    if ((((~bits32 (T.lt, s - k) | ~bits32 (T.lt, e + 1)) & kb32) != 0u) || len < mprime) return false;
+    const u32 l32 = bits32 (T.code, 2 * (s - k)) & km32, r32 = bits32 (T.code, 2 * (e + 1)) & km32;
+    const u32 cb = (T.code[s >> 4] >> (2 * (s & 15))) & 3u;
+    if (cb < 2u) { c0 = l32; c1 = r32; base = cb; flag = 1u; }
+    else { c0 = revcomp_k32 (r32, k); c1 = revcomp_k32 (l32, k); base = 3u - cb; flag = 2u; }
+  }
+  else {                                                // the tract runs past the window: walk the stream (rare)
+    const u32 b = stream_byte (seq, n_bytes, gs);
+    long ge = gs;
+    while (stream_byte (seq, n_bytes, ge + 1) == b) ge++;
+    len = ge - gs + 1;
+    u64 left, right, cc0, cc1; u32 linv, rinv;
+    // (outside the window bytes may be anything: non-ACGTU flank bases pack as 0 in both orientations)
+    if (!flanks_from_stream (seq, n_bytes, gs, ge, k, left, right, linv, rinv) || len < mprime) return false;
+    canonicalise (left, right, linv, rinv, byte_code (b), k, cc0, cc1, base, flag);
+    c0 = (u32) cc0; c1 = (u32) cc1;
+  }
+  const u64 rec = pack_rec1 (c0, c1, base, (u32) ((u64) len & 0x3FFull), flag);
+  lo = (u32) rec; hi = (u32) (rec >> 32);
+  return true;
+}
+
 template <int W>
-__global__ __launch_bounds__ (FK_BLOCK, 6)
+__global__ __launch_bounds__ (FK_BLOCK, FK_BLOCK * FK_WG_PER_CU / 256)
 void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_ftiles, int k, int mprime,
                        Buckets BK, DevCounters *ctr, u32 *__restrict__ slow_list, int par, int all_slow)
 {
@@ -1133,7 +1207,14 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   asm ("v_mov_b32 %0, 0x07070707" : "=v"(M07));
   asm ("v_mov_b32 %0, 0x06060606" : "=v"(M06));
   asm ("v_mov_b32 %0, 0x40404040" : "=v"(M40));
-  const u32 kb32 = (1u << k) - 1u, km32 = (k >= 16) ? 0xFFFFFFFFu : (1u << (2 * k)) - 1u;
+  u32 M55, vk, vk2, vkm, vrs, v32, vmp;                 // likewise the uniform values that phase 3 combines with per-lane data
+  asm ("v_mov_b32 %0, 0x55555555" : "=v"(M55));
+  asm ("v_mov_b32 %0, %1" : "=v"(vk) : "s"(k));
+  asm ("v_mov_b32 %0, %1" : "=v"(vk2) : "s"(2 * k));
+  asm ("v_mov_b32 %0, %1" : "=v"(vkm) : "s"((1u << (2 * k)) - 1u));     // (k <= 12 here)
+  asm ("v_mov_b32 %0, %1" : "=v"(vrs) : "s"(32 - 2 * k));
+  asm ("v_mov_b32 %0, 32" : "=v"(v32));
+  asm ("v_mov_b32 %0, %1" : "=v"(vmp) : "s"(mprime));
   const u32 own = (tid == 0 || tid >= (FK_WIN - FK_HR) / FK_UNIT) ? 0u : 0xFFFFFFFFu;   // halo lanes own no tract start
 
   if (tid == 0) {
@@ -1235,7 +1316,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       while (cand) {
         const u32 b = (u32) __ffs ((int) cand) - 1u;
         cand &= cand - 1u;
-        if (at < FK_MAXCAND) T.cand[at] = (unsigned short) (p0 + b);
+        T.cand[min (at, (u32) FK_MAXCAND)] = (unsigned short) (p0 | b);     // (entry FK_MAXCAND: spare slot for a tile that will be given up)
         at++;
       }
     }
@@ -1258,84 +1339,42 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       const long g0 = tile * (long) FK_OWN - FK_HL;
       for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
         const int ci = cb0 + tid;
-        bool have = false;
-        u64 c0 = 0, c1 = 0, pos = 0;
-        u32 base = 0, flag = 0, len10 = 0;
+        bool ok = false, general = false;
+        u32 lo = 0, hi = 0, s = 0;
         if (ci < ncand) {
-          const int s = T.cand[ci];
-          // run end: first run start after s, looked for in the next 32 positions (bit 31 set: "not found" reads as a
-          // run of 32, which takes the general path below like every run that does not fit one 32-bit window)
-          const u32 ns32 = bits32 (T.st, s + 1) | 0x80000000u;
-          const int f = __ffs ((int) ns32) - 1;
-          const int need = f + 1 + 2 * k;
-          if (need <= 32) {
-            // k letters, the run, k letters: all inside one 32-bit window of the letter plane
-            const u32 lw = ~bits32 (T.lt, s - k);
-            const bool ok = ((lw << (32 - need)) == 0u) && (f + 1 >= mprime);
-            if (ok) {
-              const u32 lwin = bits32 (T.code, 2 * (s - k));
-              const u32 rwin = bits32 (T.code, 2 * (s + f + 1));
-              u32 l32 = lwin & km32, r32 = rwin & km32;
-              const u32 cb = (k < 16) ? ((lwin >> (2 * k)) & 3u) : ((T.code[s >> 4] >> (2 * (s & 15))) & 3u);
-              if (cb < 2u) { c0 = l32; c1 = r32; base = cb; flag = 1u; }
-              else { c0 = revcomp_k32 (r32, k); c1 = revcomp_k32 (l32, k); base = 3u - cb; flag = 2u; }
-              len10 = (u32) (f + 1);
-              pos = (u64) (g0 + s);
-              have = true;
-            }
-          }
-          else {
-            // general path: run end from 64-bit windows of the run-start plane, the two flanks checked separately
-            int e = -1;
-            {
-              const u64 ns = bits64 (T.st, s + 1);
-              if (ns) e = s + __ffsll ((long long) ns) - 1;
-              else for (int p = s + 65; p < FK_WIN; p += 64) {
-                const u64 n2 = bits64 (T.st, p);
-                if (n2) { e = p + __ffsll ((long long) n2) - 2; break; }
-              }
-            }
-            const long gs = g0 + s;
-            long len;
-            bool ok;
-            u32 l32 = 0, r32 = 0, cb = 0;
-            if (e >= 0 && e + k < FK_WIN) {             // everything needed is in LDS
-              len = e - s + 1;
-              ok = (((~bits32 (T.lt, s - k) | ~bits32 (T.lt, e + 1)) & kb32) == 0u) && (len >= mprime);
-              if (ok) {
-                l32 = bits32 (T.code, 2 * (s - k)) & km32; r32 = bits32 (T.code, 2 * (e + 1)) & km32;
-                cb = (T.code[s >> 4] >> (2 * (s & 15))) & 3u;
-              }
-            }
-            else {                                      // tract runs past the window: walk the stream (rare)
-              const u32 b = stream_byte (seq, n_bytes, gs);
-              long ge = gs;
-              while (stream_byte (seq, n_bytes, ge + 1) == b) ge++;
-              len = ge - gs + 1;
-              u64 left, right; u32 linv, rinv;
-              ok = flanks_from_stream (seq, n_bytes, gs, ge, k, left, right, linv, rinv) && (len >= mprime);
-              // (outside the window bytes may be anything: non-ACGTU flank bases pack as 0 in both orientations)
-              cb = byte_code (b);
-              if (ok) {
-                u64 cc0, cc1;
-                canonicalise (left, right, linv, rinv, cb, k, cc0, cc1, base, flag);
-                c0 = cc0; c1 = cc1; len10 = (u32) ((u64) len & 0x3FFull); pos = (u64) gs; have = true; ok = false;
-              }
-            }
-            if (ok) {
-              if (cb < 2u) { c0 = l32; c1 = r32; base = cb; flag = 1u; }
-              else { c0 = revcomp_k32 (r32, k); c1 = revcomp_k32 (l32, k); base = 3u - cb; flag = 2u; }
-              len10 = (u32) ((u64) len & 0x3FFull);
-              pos = (u64) gs;
-              have = true;
-            }
-          }
+          // Straight-line path for a tract whose k + length + k positions fit one 32-bit window (everything else is
+          // `general`).  The windows depend on s alone, so all their LDS reads are in flight together: run starts from
+          // s + 1, letters from s - k, and 64 bits of codes from s - k (left flank, tract, right flank).
+          s = T.cand[ci];
+          const u32 q = s + 1u, u = s - vk;
+          const u32 *ps = &T.st[q >> 5], *pl = &T.lt[u >> 5], *pc = &T.code[u >> 4];
+          const u32 s0 = ps[0], s1 = ps[1], l0 = pl[0], l1 = pl[1], w0 = pc[0], w1 = pc[1], w2 = pc[2];
+          // run end: first run start after s (bit 31 set: "none in 32 positions" reads as a run of 32, which is general)
+          const u32 len = (u32) __builtin_ctz (__builtin_amdgcn_alignbit (s1, s0, q) | 0x80000000u) + 1u;
+          const u32 need = len + vk2;                      // k letters, the tract, k letters
+          general = need > 32u;
+          const u32 notl = ~__builtin_amdgcn_alignbit (l1, l0, u);
+          ok = !general && ((notl << (v32 - need)) == 0u) && (len >= vmp);
+          const u32 sh = u + u;
+          const u32 clo = __builtin_amdgcn_alignbit (w1, w0, sh), chi = __builtin_amdgcn_alignbit (w2, w1, sh);
+          const u32 l = clo & vkm;
+          const u32 cb = (clo >> vk2) & 3u;                // the tract's base
+          const u32 r = (u32) ((((u64) chi << 32) | clo) >> (vk2 + len + len)) & vkm;
+          // canonical orientation (reference: src/hopo_counter.c:233-246): T / G tracts store the reverse complement
+          const u32 rcl = revcomp_v32 (l, M55, vrs), rcr = revcomp_v32 (r, M55, vrs);
+          const bool rev = cb >= 2u;
+          const u32 c0 = rev ? rcr : l, c1 = rev ? rcl : r;
+          // base << 2 | flag << 3 by table look-up on cb: A (0, fwd) 8, C (1, fwd) 12, G (-> C, rev) 20, T (-> A, rev) 16
+          const u32 fld = __builtin_amdgcn_perm (0u, 0x10140C08u, cb | 0x0C0C0C00u);
+          lo = c1 | (len << 24);
+          hi = c0 | (fld << 24);
         }
+        if (general) ok = fast_general_tract (T, seq, n_bytes, g0, (int) s, k, mprime, lo, hi);
         STAMP (6);
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
-        if (have) asm volatile ("" :: "v"(c0), "v"(c1), "v"(base), "v"(len10), "v"(flag), "v"(pos));
+        if (ok) asm volatile ("" :: "v"(lo), "v"(hi));
 #else
-        sink.put (have, c0, c1, base, len10, flag, pos, (u32) min (ncand - cb0, FK_BLOCK));
+        sink.put1 (ok, lo, hi, (u32) min (ncand - cb0, FK_BLOCK));
 #endif
         STAMP (7);
       }
@@ -1439,11 +1478,11 @@ __global__ void table_relayout_kernel (const u32 *__restrict__ old, u32 old_maxj
 #define AG1_S        8192
 #define AG1_CLOSE_AT 4864                // typical overshoot: a few keys; worst case one per lane (1024): 72 % full
 #define AG1_R        4                   // records in flight per lane
-#define AG1_MARK     (~0ull)             // a key is at most 59 bits
+#define AG1_MARK     (~0ull)             // a key has bits 59-63 clear
 
 struct Agg1Lds
 {
-  u64 key[AG1_S];                       // record >> 2 (never 0: the stored length of a tract is >= 2)
+  u64 key[AG1_S];                       // record without its strand flag (never 0: the base next to an A tract is not A)
   u32 cnt[2 * AG1_S];                   // per slot: records seen on the forward / on the reverse strand
   u32 chunk[AG_NCH];                    // the bucket's chunk ids
   u32 n_claimed, n_ovf, total;
@@ -1457,7 +1496,6 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 bkt = blockIdx.x;
   u32 n = BK.cursors[bkt];
-  const u64 km = kmask (k);
   if (n) for (u32 j = (u32) tid; j <= chunk_of_pos (BK, n - 1u) && j < AG_NCH; j += AG_BLOCK) L.chunk[j] = bucket_chunk_id (BK, bkt, j, false, nullptr);
   auto chunk_id = [&] (u32 j) { return j < AG_NCH ? L.chunk[j] : bucket_chunk_id (BK, bkt, j, false, nullptr); };
 
@@ -1540,11 +1578,11 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
 #pragma unroll
         for (int r = 0; r < AG1_R; r++) {
           const u64 cur = w[r];
-          if (((valid >> r) & 1u) && (cur & 3ull) != 3ull) {
-            const u64 key = cur >> 2;
+          if (((valid >> r) & 1u) && ((cur >> R1_FLAG_SHIFT) & 3ull) != 3ull) {
+            const u64 key = cur & R1_KEY_MASK;
             const u32 pair = home (key);
             const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *> (&L.key[2 * pair]);
-            if (kk.x == key || kk.y == key) atomicAdd (&L.cnt[4 * pair + (kk.x == key ? 0u : 2u) + ((u32) (cur >> 1) & 1u)], 1u);
+            if (kk.x == key || kk.y == key) atomicAdd (&L.cnt[4 * pair + (kk.x == key ? 0u : 2u) + ((u32) (cur >> (R1_FLAG_SHIFT + 1)) & 1u)], 1u);
             else todo |= 1u << r;
           }
         }
@@ -1552,12 +1590,12 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
         u32 probes = 0;
         u32 r = todo ? (u32) __ffs ((int) todo) - 1u : 0u;
         u64 cur = (r == 0u) ? w[0] : (r == 1u) ? w[1] : (r == 2u) ? w[2] : w[3];
-        u32 pair = home (cur >> 2);
+        u32 pair = home (cur & R1_KEY_MASK);
         while (todo) {
           bool adv = false, left = false;
           {
-            const u64 key = cur >> 2;
-            const u32 strand = (u32) (cur >> 1) & 1u;
+            const u64 key = cur & R1_KEY_MASK;
+            const u32 strand = (u32) (cur >> (R1_FLAG_SHIFT + 1)) & 1u;
             const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *> (&L.key[2 * pair]);
             if (kk.x == key || kk.y == key) { atomicAdd (&L.cnt[4 * pair + (kk.x == key ? 0u : 2u) + strand], 1u); adv = true; }
             else {
@@ -1589,7 +1627,7 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
             if (todo) {
               r = (u32) __ffs ((int) todo) - 1u;
               cur = (r == 1u) ? w[1] : (r == 2u) ? w[2] : w[3];
-              pair = home (cur >> 2);
+              pair = home (cur & R1_KEY_MASK);
             }
           }
         }
@@ -1611,8 +1649,9 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
         const u64 cnt = ((u64) cf + (u64) cr) & 0xFFFFFull;
         const int scnt = (cnt & 0x80000ull) ? (int) cnt - 0x100000 : (int) cnt;
         if (remove_biased ? (flag == 3ull) : (scnt > 1)) {
-          const u64 key = L.key[slot];                  // len | ctx1 << 10 | ctx0 << (10 + 2k) | base << (10 + 4k)
-          metas[r] = ((key >> (10 + 4 * k)) & 1ull) | ((key & 0x3FFull) << TJ_META_LEN_SHIFT) | (cnt << TJ_META_COUNT_SHIFT) |
+          const u64 key = L.key[slot];                  // the record's fields (see pack_rec1)
+          const u64 len10 = ((key >> 24) & 0xFFull) | (((key >> 56) & 3ull) << 8);
+          metas[r] = ((key >> 58) & 1ull) | (len10 << TJ_META_LEN_SHIFT) | (cnt << TJ_META_COUNT_SHIFT) |
                      (0xffeull << TJ_META_MISM_SHIFT) | (flag << TJ_META_FLAG_SHIFT);
           mine++;
         }
@@ -1630,7 +1669,7 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     for (int r = 0; r < AG1_S / AG_BLOCK; r++)
       if (metas[r]) {
         const u64 key = L.key[tid + r * AG_BLOCK];
-        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (key >> (10 + 2 * k)) & km; q[1] = (key >> 10) & km; q[2] = metas[r]; }
+        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (key >> 32) & 0xFFFFFFull; q[1] = key & 0xFFFFFFull; q[2] = metas[r]; }
         else fin->overflow = 1u;
         at++;
       }
@@ -3026,7 +3065,8 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
   // fast kernel: tiles of FK_OWN tract starts, two workgroups resident per CU; the list of the tiles it leaves to the generic
   // kernel (every one of them at worst), which that kernel covers with ceil (FK_OWN / TJ_SB_TILE) of its own tiles each
   const long n_ftiles = (long) ((n_bytes + FK_OWN - 1) / FK_OWN);
-  const int fgrid = (int) std::min<long> (n_ftiles, (long) c->n_cu * 3);
+  static const int fwg = getenv ("TATAJUBA_AMD_FGRID") ? atoi (getenv ("TATAJUBA_AMD_FGRID")) : FK_WG_PER_CU;     // (experiment hook: workgroups per CU)
+  const int fgrid = (int) std::min<long> (n_ftiles, (long) c->n_cu * fwg);
   const int lgrid = (int) std::min<long> (n_ftiles * ((FK_OWN + TJ_SB_TILE - 1) / TJ_SB_TILE), (long) c->n_cu * TJ_SB_WG_PER_CU);
   if (!rc && c->W == 1 && c->fast_mode) rc = ensure (c->slow, (size_t) n_ftiles * 4 + 64, c->stream);
   if (rc) return rc;
