@@ -9,11 +9,18 @@ k=10, min_tract=3, strand-bias filter on, min_coverage=5.  With N>1 GPUs every r
 path has: an all-gatherv (RCCL) of the per-sample histograms and their merge, run on a second stream under the next
 sample's scan (the last one inside the timed region).
 
+`--gpus N` without a launcher (the driver's command shape): the parent starts N fresh child processes, one rank per GPU,
+before anything in it has touched a GPU, relays rank 0's JSON line and exits with the children's return code.
+`--config {2,3,4,5}` picks one of BASELINE.json's configurations (numbered as in SURVEY.md 8(d): 2 = configs[1], the
+headline, and the default); `config.workload` names what was really run.
+
 Prints ONE JSON line on rank 0.  The CPU oracle is used only for the cpu_baseline leg (never in the timed GPU path).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +30,119 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+# BASELINE.json configurations, numbered as in SURVEY.md 8(d) (config N = BASELINE.json configs[N - 1]); inputs per
+# SURVEY 8(d)'s recipe.  Config 5 (5 M reads of 2-20 kb = 55 GB per sample) runs at 1/10 scale per sample, as 8(d) allows.
+CONFIGS = {
+    2: dict(reads=10_000_000, read_len=150, read_len_max=0, genome=5_000_000, kmer=10, min_tract=3,
+            label="BASELINE.json configs[1]: 1 sample, 10 M x 150 bp single-end, k=10 min_tract=3"),
+    3: dict(reads=100_000_000, read_len=150, read_len_max=0, genome=50_000_000, kmer=15, min_tract=4,
+            label="BASELINE.json configs[2]: 1 sample, 50 M pairs = 100 M x 150 bp reads, k=15 min_tract=4, strand-bias filter"),
+    4: dict(reads=40_000_000, read_len=150, read_len_max=0, genome=20_000_000, kmer=15, min_tract=4,
+            label="BASELINE.json configs[3]: one sample of 20 M pairs = 40 M x 150 bp reads per GPU, k=15 min_tract=4, all-gatherv merge"),
+    5: dict(reads=500_000, read_len=2000, read_len_max=20000, genome=100_000_000, kmer=25, min_tract=4,
+            label="BASELINE.json configs[4] at 1/10 scale per sample: 0.5 M long reads of 2-20 kb per GPU, k=25 min_tract=4"),
+}
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: one child process per rank (fresh processes: nothing here has touched a GPU)."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def rehearse(args):
+    """Launch plumbing only (no GPU work, no throughput): rendezvous, barrier, max over ranks, one JSON line from rank 0.
+    What the CPU tests run; a product run never takes this path."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "max_over_ranks": float(t.item()), "value": None,
+                          "config": {"workload": workload_label(args)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def workload_label(args):
+    """names what the arguments really are: a BASELINE.json configuration, or 'custom'"""
+    for n, c in CONFIGS.items():
+        if all(getattr(args, kk) == c[kk] for kk in ("reads", "read_len", "read_len_max", "genome", "kmer", "min_tract")):
+            return c["label"] + f" (SURVEY 8d config {n})"
+    return "custom workload (no BASELINE.json configuration)"
+
+
+def io_stages(tj, host, args, k, m, L):
+    """The two throughputs around the HBM-resident one, on a bounded part of the same sample, never `value`:
+    a pinned host-resident stream through tjamd_scan_host (PCIe-inclusive) + finalise, and a plain FASTQ file through
+    new_or_append_hopo_counter_from_file + finalise_hopo_counter (parse + copy + scan + finalise)."""
+    import ctypes as C
+    import tempfile
+    from tatajuba_amd import capi
+    res = {}
+    n_io = min(args.io_reads, args.reads)
+    if args.read_len_max > L:                               # ragged reads: cut after the n_io-th delimiter
+        ends = np.flatnonzero(host[: min(host.size, n_io * (args.read_len_max + 1))] == 10)
+        n_io = min(n_io, ends.size)
+        part = host[: ends[n_io - 1] + 1]
+    else:
+        part = host[: n_io * (L + 1)]
+    lib = capi.lib()
+    pin = lib.tjamd_host_alloc(part.size)
+    C.memmove(pin, part.ctypes.data, part.size)
+    c = tj.Counter(k)
+    best = 1e9
+    for rep in range(3):
+        c.reset()
+        t = time.perf_counter()
+        if lib.tjamd_scan_host(c._h, C.c_void_p(pin), part.size, m):
+            raise SystemExit("tjamd_scan_host failed")
+        c.finalise(1, args.min_coverage)
+        best = min(best, time.perf_counter() - t)
+    c.close()
+    lib.tjamd_host_free(C.c_void_p(pin))
+    res["from_host"] = {"reads_per_s": n_io / best, "GBps": part.size / best / 1e9, "seconds": best, "reads": n_io,
+                        "note": "pinned host stream -> tjamd_scan_host (host-to-device copy included) + finalise"}
+    tmp = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
+    fq = os.path.join(tmp, "bench.fq")
+    reads = bytes(part).split(b"\n")[:-1]
+    with open(fq, "wb") as f:
+        for i in range(0, len(reads), 100000):
+            f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (j, reads[j], b"I" * len(reads[j])) for j in range(i, min(len(reads), i + 100000))))
+    opt = tj.Options.defaults(k, m, args.min_coverage, True)
+    best = 1e9
+    for rep in range(2):
+        t = time.perf_counter()
+        h = tj.HopoCounter.new_or_append_from_file(None, fq, opt)
+        h.finalise()
+        best = min(best, time.perf_counter() - t)
+        h.delete()
+    res["from_file"] = {"reads_per_s": len(reads) / best, "file_MB": os.path.getsize(fq) / 1e6, "seconds": best, "reads": len(reads),
+                        "note": "plain FASTQ -> new_or_append_hopo_counter_from_file (multi-threaded feeder) + finalise_hopo_counter"}
+    os.remove(fq)
+    os.rmdir(tmp)
+    return res
 
 
 def main():
@@ -39,7 +159,20 @@ def main():
     ap.add_argument("--min-coverage", type=int, default=5)
     ap.add_argument("--cpu-reads", type=int, default=2_000_000, help="reads of the same sample timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=None,
+                    help="a BASELINE.json configuration (SURVEY 8d numbering; 2 = configs[1] = the headline = the default sizes)")
+    ap.add_argument("--no-io-stages", action="store_true", help="skip the host-memory and FASTQ-file throughputs (stages.from_host / from_file)")
+    ap.add_argument("--io-reads", type=int, default=2_000_000, help="reads of the sample used for stages.from_host / from_file")
+    ap.add_argument("--rehearse", action="store_true", help="launch plumbing only, no GPU work (CPU tests)")
     args = ap.parse_args()
+    if args.config is not None:
+        for kk, vv in CONFIGS[args.config].items():
+            if kk != "label":
+                setattr(args, kk, vv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.rehearse:
+        return rehearse(args)
 
     import torch
     import tatajuba_amd as tj
@@ -48,8 +181,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or tj.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     ndev = torch.cuda.device_count()
@@ -191,21 +323,23 @@ def main():
     dominant = "scan" if scan_avg >= fin_avg else "finalise"
     # HBM bytes per launch from the PMC passes of the same command (tools/pmc_traffic.py -> profiles/; rocprofv3 cannot
     # run inside the timed process), only when they were taken on this workload
-    traffic, traffic_rw = {}, {}
+    scan_kernel = "scan_fast_kernel<1>" if k <= 12 else ("scan_bins_kernel<2>" if k <= 28 else "scan_bins_kernel<4>")
+    traffic, traffic_src = None, None
+    prof = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
     try:
-        tj_prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-        if args.reads == 10_000_000 and L == 150 and k == 10 and m == 3:
-            traffic = {kk: vv["hbm_bytes"] for kk, vv in tj_prof.items() if isinstance(vv, dict)}
-            traffic_rw = {kk: (vv["hbm_read_bytes"], vv["hbm_write_bytes"]) for kk, vv in tj_prof.items() if isinstance(vv, dict)}
+        tj_prof = json.load(open(prof))
+        w = tj_prof.get("_workload", {})
+        if (w.get("reads"), w.get("read_len"), w.get("kmer"), w.get("min_tract")) == (args.reads, L, k, m) and args.read_len_max <= L:
+            traffic = {kk: vv for kk, vv in tj_prof.items() if isinstance(vv, dict) and "hbm_bytes" in vv}
+            traffic_src = "profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py), per launch"
     except (OSError, ValueError, KeyError):
         pass
-    roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None}
+    roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_src}
     if dominant == "scan":
-        roof.update({"kernel": "scan_bins_kernel<1>" if k <= 12 else ("scan_bins_kernel<2>" if k <= 28 else "scan_bins_kernel<4>"),
-                     "achieved": scan_gbs, "frac": scan_gbs / HBM_PEAK_GBS, "ms": scan_avg, "algorithmic_bytes": scan_bytes,
-                     "traffic": traffic.get("scan_bins_kernel<1>") if k <= 12 else None})
-        if k <= 12 and "scan_bins_kernel<1>" in traffic_rw:   # reads = the stream (no re-reads); writes = the raw records leaving the kernel
-            roof["traffic_read"], roof["traffic_write"] = traffic_rw["scan_bins_kernel<1>"]
+        roof.update({"kernel": scan_kernel, "achieved": scan_gbs, "frac": scan_gbs / HBM_PEAK_GBS, "ms": scan_avg, "algorithmic_bytes": scan_bytes})
+        if traffic and scan_kernel in traffic:              # reads = the stream (no re-reads); writes = the raw records leaving the kernel
+            roof["traffic"] = traffic[scan_kernel]["hbm_bytes"]
+            roof["traffic_read"], roof["traffic_write"] = traffic[scan_kernel]["hbm_read_bytes"], traffic[scan_kernel]["hbm_write_bytes"]
     else:
         roof.update({"kernel": "finalise (aggregate_kernel dominates)", "achieved": fin_gbs, "frac": fin_gbs / HBM_PEAK_GBS,
                      "ms": fin_avg, "algorithmic_bytes": fin_bytes})
@@ -216,15 +350,19 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/u64", "data": "synthetic",
         "config": {"workload": f"{world} sample(s) x {args.reads} synthetic {L} bp single-end reads, genome {args.genome} bp, "
-                               f"k={k} min_tract={m} remove_biased=1 min_coverage={args.min_coverage} (BASELINE.json configs[1] per GPU)",
+                               f"k={k} min_tract={m} remove_biased=1 min_coverage={args.min_coverage}"
+                               + (f", read length uniform in [{L}, {args.read_len_max}]" if args.read_len_max > L else "") + " -- " + workload_label(args),
                    "reads_per_gpu": args.reads, "raw_records_per_gpu": int(raw), "kept_records": int(kept),
                    "parallelism": f"sample-per-gpu x{world}" + (", histogram exchange (all-gatherv + merge) overlapped with the next sample's scan" if world > 1 else "")},
         "roofline": roof,
         "stages": {"scan": {"ms": scan_avg, "algorithmic_GBps": scan_gbs, "frac_of_hbm_peak": scan_gbs / HBM_PEAK_GBS,
-                            "reads_per_s": args.reads / (scan_avg * 1e-3)},
+                            "reads_per_s": args.reads / (scan_avg * 1e-3), "kernel": scan_kernel,
+                            "note": "stream resident in HBM (the throughput `value` is quoted on)"},
                    "finalise": {"ms": fin_avg, "algorithmic_GBps": fin_gbs, "frac_of_hbm_peak": fin_gbs / HBM_PEAK_GBS}},
     }
 
+    if rank == 0 and world == 1 and not args.no_io_stages:
+        out["stages"].update(io_stages(tj, host, args, k, m, L))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orc                             # checker / baseline only
         n_cpu = min(args.cpu_reads, args.reads)
@@ -238,7 +376,8 @@ def main():
         out["cpu_baseline"] = {"value": n_cpu / (t3 - t1), "unit": "reads/s", "cores": 1, "kind": "port",
                                "sample": f"first {n_cpu} reads of the same sample; scan {t2 - t1:.2f} s + sort/dedupe/filter {t3 - t2:.2f} s "
                                          f"on 1 core (the reference runs one thread per sample: src/genome_set.c:66-68); "
-                                         f"parse/inflate excluded on both sides",
+                                         f"parse/inflate excluded on both sides; the subset flatters the CPU a little: its qsort is "
+                                         f"n log n and its depth is {args.reads / max(n_cpu, 1):.0f}x lower than the full sample's",
                                "host_cores_available": os.cpu_count()}
         # the reference's only parallel loop is over samples (OpenMP, src/genome_set.c:66-94): the same CPU path on P
         # samples at once (P threads, one slice of the stream each) is what a whole host delivers

@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_HERE, "libtatajuba_amd.so")
-_SOURCES = ["hopo_device.hip", "hopo_host.c", "fastq_reader.c", "fastq_reader.h", "synth.c", "exports.map", "Makefile",
+_SOURCES = ["hopo_device.hip", "hopo_host.c", "fastq_reader.c", "fastq_reader.h", "feeder.c", "feeder.h", "synth.c", "exports.map", "Makefile",
             os.path.join("..", "..", "include", "tatajuba_amd.h"), os.path.join("..", "..", "include", "tatajuba_hopo.h")]
 
 

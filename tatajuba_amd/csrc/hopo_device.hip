@@ -858,7 +858,7 @@ __device__ __forceinline__ u32 bucket_chunk_id (const Buckets &B, u32 b, u32 j, 
       __builtin_amdgcn_s_sleep (4);
       ch = __hip_atomic_load (e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (ch == TJ_EMPTY && ctr) ctr->overflow = 1u;
+    if (ch == TJ_EMPTY && ctr) ctr->overflow = 2u;          // (2: waited in vain for a chunk id -- a liveness problem, not a full pool)
   }
   return ch >= TJ_NOCHUNK ? TJ_NOCHUNK : ch;
 }
@@ -2939,6 +2939,9 @@ static int apply_counter_copies (tjamd_counter *c)
   long total = 0;
   u64 mx = 0;
   for (int b = 0; b < TJ_P; b++) { total += c->h_cursors[b]; mx = std::max<u64> (mx, c->h_cursors[b]); }
+  if (c->h_ctr->overflow == 2u)
+    return set_err (TJAMD_ERR_HIP, "a chunk of raw record storage was claimed but its id was never published (waited %u polls): "
+                    "the claiming workgroup did not make progress -- please report; scanning again usually succeeds", (unsigned) TJ_SPIN_MAX);
   if (c->h_ctr->overflow)
     return set_err (TJAMD_ERR_CAPACITY, "raw record storage exhausted (%u of %u chunks handed out, fullest bucket %llu records): "
                     "raise TATAJUBA_AMD_BUCKET_SLACK (now %.1f) and scan again", c->h_cursors[TJ_P], c->pool_chunks, (unsigned long long) mx, c->slack);

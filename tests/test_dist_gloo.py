@@ -85,3 +85,21 @@ def test_merge_host_order_and_counts():
     first = (int(da["base"][0]), int(a["ctx0"][0]), int(a["ctx1"][0]), int(da["length"][0]))
     assert mat[tup.index(first), 0] == da["count"][0]
     assert mat.shape == (len(tup), 2) and (mat >= 0).all() and (mat.sum(axis=1) > 0).all()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` as the driver calls it (no external launcher): N fresh ranks, one JSON line from rank 0,
+    the children's return code -- rehearsed without a GPU (`--rehearse`: rendezvous, barrier and reduction only)."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse", "--config", "4"], env=env, stdout=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["max_over_ranks"] == 2.0
+    assert "configs[3]" in d["config"]["workload"]                          # the label follows the arguments
+    r = subprocess.run([sys.executable, bench, "--rehearse", "--kmer", "13"], env=env, stdout=subprocess.PIPE, timeout=300)
+    assert "custom workload" in json.loads(r.stdout.decode().splitlines()[-1])["config"]["workload"]

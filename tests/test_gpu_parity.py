@@ -78,7 +78,7 @@ def check_finalise(stream_parts, k, m, remove_biased, min_cov):
 # ---- known answers through the drop-in CPU entry ------------------------------------------------------------------
 
 def test_known_answers_update_from_seq(known_answers):
-    for case in known_answers["scan"]:
+    for case in known_answers["figure"] + known_answers["scan"]:      # "figure": the reference's own drawing (recipe/200322_001.png)
         h = tj.HopoCounter.new(case["k"])
         h.update_from_seq(case["seq"], case["m"])
         e = h.elems()
@@ -92,6 +92,27 @@ def test_known_answers_update_from_seq(known_answers):
         o.scan_seq(case["seq"], case["m"])
         assert e.tobytes() == o.elems().tobytes()          # all 40 bytes of every element
         h.delete()
+
+
+def test_reference_figure_through_the_bucket_scan(known_answers):
+    """The three tracts of the reference's figure (recipe/200322_001.png, README.md:218-232), many times over, through the
+    bucket scan (tiles of the fast kernel and of the generic one): exactly the drawn contexts, bases, lengths and strands."""
+    fig = known_answers["figure"]
+    reads = [c["seq"] for c in fig] * 4000
+    random.Random(5).shuffle(reads)
+    s = np.frombuffer(("\n".join(reads) + "\n").encode(), np.uint8)
+    c = tj.Counter(3)
+    c.scan_host(s, 2)
+    got = c.download_raw()
+    c.close()
+    d = tj.decode_meta(got["meta"])
+    seen = {}
+    for i in range(len(got)):
+        key = (int(d["base"][i]), int(d["length"][i]), int(d["canon_flag"][i]), int(got["ctx0"][i]), int(got["ctx1"][i]))
+        seen[key] = seen.get(key, 0) + 1
+    exp = {(r[0], r[1], r[3], int(r[4], 16), int(r[5], 16)): 4000 for c in fig for r in c["records"]}
+    assert seen == exp
+    assert len(got) == len(as_records(oracle_raw(s, 3, 2).elems()))
 
 
 def test_stale_context_and_undefined(known_answers):

@@ -1,5 +1,6 @@
-"""The CPU oracle against every known-answer vector there is for this path (tests/golden/known_answers.json:
-the reference README's stored-name example and SURVEY.md 9.7's outputs of the unmodified reference), plus a
+"""The CPU oracle against every known-answer vector there is for this path (tests/golden/known_answers.json).
+Reference-held: the three tracts of the reference's figure recipe/200322_001.png and the names README.md:226-230 gives
+them.  Not reference-held (they document what the oracle was written to): SURVEY.md 9.7's probe outputs.  Plus a
 cross-check of the C state machine against an independent closed-form statement on random strings."""
 import os
 import random
@@ -19,7 +20,7 @@ def records_of(o, k):
 
 
 def test_scan_known_answers(known_answers):
-    for c in known_answers["scan"]:
+    for c in known_answers["figure"] + known_answers["scan"]:
         o = orc.Oracle(c["k"])
         o.scan_seq(c["seq"], c["m"])
         got = records_of(o, c["k"])
@@ -34,15 +35,23 @@ def test_scan_known_answers(known_answers):
         assert (e["loc_ref_id"] == -1).all() and (e["loc_pos"] == -1).all() and (e["loc_last"] == -1).all()
 
 
-def test_readme_canonical_names(known_answers):
-    # README.md:226-230: CCG-A-GAT, its reverse strand and the C tract are stored as these three names
-    names = set()
-    for seq in ("TTCCGAAAAGATTT", "TTATCAAAACCGTT", "TTCCGCCCCGATTT"):
-        o = orc.Oracle(3)
-        o.scan_seq(seq, 3)
-        (r,) = [x for x in records_of(o, 3) if x[1] == 4]
-        names.add(orc.name_of(r[4], r[5], r[0], 3))
-    assert names == set(known_answers["readme"][0]["names_stored"])
+def test_reference_figure_and_readme_names(known_answers):
+    """recipe/200322_001.png draws, for the reads CCG-AAA-GAT, CCG-TTT-GAT and CCG-CC-GAT, the stored context, base and
+    length; README.md:226-230 prints the stored names.  The T tract is the only reference-held statement of the reverse
+    complement canonicalisation (src/hopo_counter.c:239-246): context ATC|CGG, base A, strand flag 2."""
+    drawn = {"CCGAAAGAT": ("CCG", "GAT", "A", 3, 1), "CCGTTTGAT": ("ATC", "CGG", "A", 3, 2), "CCGCCGAT": ("CCG", "GAT", "C", 2, 1)}
+    names = []
+    for c in known_answers["figure"]:
+        o = orc.Oracle(c["k"])
+        o.scan_seq(c["seq"], c["m"])
+        (r,) = records_of(o, c["k"])
+        left, right, base, length, flag = drawn[c["seq"]]
+        name = orc.name_of(r[4], r[5], r[0], c["k"])
+        assert name == "%s.%s.%s" % (left, base, right) and r[1] == length and r[3] == flag and r[2] == 0
+        names.append(name)
+    readme = known_answers["readme"][0]["names_stored"]
+    # the README's second name, ATC.A.CCG, is not what its own figure (and the code) stores: ATC.A.CGG -- see the note in the JSON
+    assert names[0] == readme[0] and names[2] == readme[2] and names[1] == "ATC.A.CGG" and readme[1] == "ATC.A.CCG"
 
 
 def test_stale_context_quirk(known_answers):

@@ -1,20 +1,21 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): rocprofv3 evidence for profiles/.  Timings and counters in separate passes.
-#   gpurun -- 'bash tools/collect_profiles.sh'   -> gpurun_out/r01/*
+#   gpurun -- 'bash tools/collect_profiles.sh [tag] [bench args...]'   -> gpurun_out/<tag>/*      (tag defaults to r02)
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r01
+TAG=${1:-r02}; shift || true
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2> $O/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-io-stages "$@" > $O/bench_under_rocprof.json 2> $O/kt.err
 echo "kernel trace done" > $O/progress.txt
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/fetch.out 2> $O/fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-io-stages "$@" > $O/fetch.out 2> $O/fetch.err
 echo "fetch done" >> $O/progress.txt
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/write.out 2> $O/write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-io-stages "$@" > $O/write.out 2> $O/write.err
 echo "write done" >> $O/progress.txt
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq1 -o sq1 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/sq1.out 2> $O/sq1.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq1 -o sq1 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-io-stages "$@" > $O/sq1.out 2> $O/sq1.err
 echo "sq1 done" >> $O/progress.txt
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/sq2 -o sq2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/sq2.out 2> $O/sq2.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/sq2 -o sq2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-io-stages "$@" > $O/sq2.out 2> $O/sq2.err
 echo "sq2 done" >> $O/progress.txt
-python3 $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+python3 $R/bench.py "$@" > $O/bench_plain.json 2> $O/bench_plain.err
 find $O -name "*.csv" | head -20
