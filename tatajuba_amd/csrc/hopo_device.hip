@@ -960,7 +960,7 @@ struct StageSink
     bound += round_max;
     if (have) {
       const u32 at = atomicAdd (&L.n, 1u);
-      L.rec[at] = ((u64) hi << 32) | lo;
+      L.rec[at * WS] = ((u64) hi << 32) | lo;             // (W == 1)
       L.bin[at] = (unsigned char) bucket_of_rec1 (lo, hi);
     }
   }
@@ -1146,45 +1146,68 @@ __device__ __forceinline__ u32 revcomp_v32 (u32 x, u32 m55, u32 rs)
   return z >> rs;
 }
 
-// A tract that does not fit the straight-line path of scan_fast_kernel's phase 3 (k + length + k > 32 positions): run end
-// from 64-bit windows of the run-start plane, flanks checked separately, and past the window's end a walk through the
-// stream in global memory -- scan_tiles' logic on this kernel's planes.  Returns false if the tract is not recorded.
-__device__ __noinline__ bool fast_general_tract (const FastLds &T, const uint8_t *__restrict__ seq, long n_bytes, long g0, int s, int k, int mprime,
-                                                 u32 &lo, u32 &hi)
+// Phase 3 of scan_fast_kernel for any k: run end from the run-start plane (32 positions first, then 64-bit windows), the
+// two flanks checked against the letter plane and pulled out of the code plane separately (32-bit arithmetic for
+// k <= 16), and past the window's end a walk through the stream in global memory -- scan_tiles' logic on this kernel's
+// planes.  Returns false if the tract is not recorded.
+template <bool K32>
+__device__ __forceinline__ bool fast_tract (const FastLds &T, const uint8_t *__restrict__ seq, long n_bytes, long g0, int s, int k, int mprime,
+                                            u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
 {
-  const u32 kb32 = (1u << k) - 1u, km32 = (k >= 16) ? 0xFFFFFFFFu : (1u << (2 * k)) - 1u;
   int e = -1;
   {
-    const u64 ns = bits64 (T.st, s + 1);
-    if (ns) e = s + __ffsll ((long long) ns) - 1;
-    else for (int p = s + 65; p < FK_WIN; p += 64) {
-      const u64 n2 = bits64 (T.st, p);
-      if (n2) { e = p + __ffsll ((long long) n2) - 2; break; }
+    const u32 ns32 = bits32 (T.st, s + 1);
+    if (ns32) e = s + __ffs ((int) ns32) - 1;
+    else {
+      const u64 ns = bits64 (T.st, s + 1);
+      if (ns) e = s + __ffsll ((long long) ns) - 1;
+      else for (int p = s + 65; p < FK_WIN; p += 64) {
+        const u64 n2 = bits64 (T.st, p);
+        if (n2) { e = p + __ffsll ((long long) n2) - 2; break; }
+      }
     }
   }
   const long gs = g0 + s;
   long len;
-  u32 c0, c1, base, flag;
   if (e >= 0 && e + k < FK_WIN) {                       // everything needed is in LDS
     len = e - s + 1;
+    const u32 kb32 = (k >= 32) ? 0xFFFFFFFFu : (1u << k) - 1u;
     if ((((~bits32 (T.lt, s - k) | ~bits32 (T.lt, e + 1)) & kb32) != 0u) || len < mprime) return false;
-    const u32 l32 = bits32 (T.code, 2 * (s - k)) & km32, r32 = bits32 (T.code, 2 * (e + 1)) & km32;
     const u32 cb = (T.code[s >> 4] >> (2 * (s & 15))) & 3u;
-    if (cb < 2u) { c0 = l32; c1 = r32; base = cb; flag = 1u; }
-    else { c0 = revcomp_k32 (r32, k); c1 = revcomp_k32 (l32, k); base = 3u - cb; flag = 2u; }
+    if (K32 || k <= 16) {
+      const u32 km32 = (k >= 16) ? 0xFFFFFFFFu : (1u << (2 * k)) - 1u;
+      const u32 l32 = bits32 (T.code, 2 * (s - k)) & km32, r32 = bits32 (T.code, 2 * (e + 1)) & km32;
+      if (cb < 2u) { c0 = l32; c1 = r32; base = cb; flag = 1u; }
+      else { c0 = revcomp_k32 (r32, k); c1 = revcomp_k32 (l32, k); base = 3u - cb; flag = 2u; }
+    }
+    else {
+      const u64 km = kmask (k);
+      const u64 left = bits64 (T.code, 2 * (s - k)) & km, right = bits64 (T.code, 2 * (e + 1)) & km;
+      if (cb < 2u) { c0 = left; c1 = right; base = cb; flag = 1u; }
+      else { c0 = revcomp_k (right, k); c1 = revcomp_k (left, k); base = 3u - cb; flag = 2u; }
+    }
   }
   else {                                                // the tract runs past the window: walk the stream (rare)
     const u32 b = stream_byte (seq, n_bytes, gs);
     long ge = gs;
     while (stream_byte (seq, n_bytes, ge + 1) == b) ge++;
     len = ge - gs + 1;
-    u64 left, right, cc0, cc1; u32 linv, rinv;
+    u64 left, right; u32 linv, rinv;
     // (outside the window bytes may be anything: non-ACGTU flank bases pack as 0 in both orientations)
     if (!flanks_from_stream (seq, n_bytes, gs, ge, k, left, right, linv, rinv) || len < mprime) return false;
-    canonicalise (left, right, linv, rinv, byte_code (b), k, cc0, cc1, base, flag);
-    c0 = (u32) cc0; c1 = (u32) cc1;
+    canonicalise (left, right, linv, rinv, byte_code (b), k, c0, c1, base, flag);
   }
-  const u64 rec = pack_rec1 (c0, c1, base, (u32) ((u64) len & 0x3FFull), flag);
+  len10 = (u32) ((u64) len & 0x3FFull);
+  return true;
+}
+
+// the same, out of line, for the tracts that do not fit the one-word kernel's straight-line path (k + length + k > 32)
+__device__ __noinline__ bool fast_general_tract (const FastLds &T, const uint8_t *__restrict__ seq, long n_bytes, long g0, int s, int k, int mprime,
+                                                 u32 &lo, u32 &hi)
+{
+  u64 c0, c1; u32 base, len10, flag;
+  if (!fast_tract<true> (T, seq, n_bytes, g0, s, k, mprime, c0, c1, base, len10, flag)) return false;
+  const u64 rec = pack_rec1 ((u32) c0, (u32) c1, base, len10, flag);
   lo = (u32) rec; hi = (u32) (rec >> 32);
   return true;
 }
@@ -1211,8 +1234,8 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   asm ("v_mov_b32 %0, 0x55555555" : "=v"(M55));
   asm ("v_mov_b32 %0, %1" : "=v"(vk) : "s"(k));
   asm ("v_mov_b32 %0, %1" : "=v"(vk2) : "s"(2 * k));
-  asm ("v_mov_b32 %0, %1" : "=v"(vkm) : "s"((1u << (2 * k)) - 1u));     // (k <= 12 here)
-  asm ("v_mov_b32 %0, %1" : "=v"(vrs) : "s"(32 - 2 * k));
+  asm ("v_mov_b32 %0, %1" : "=v"(vkm) : "s"(W == 1 ? (1u << (2 * k)) - 1u : 0u));     // (the straight-line phase 3 is for k <= 12)
+  asm ("v_mov_b32 %0, %1" : "=v"(vrs) : "s"(W == 1 ? 32 - 2 * k : 0));
   asm ("v_mov_b32 %0, 32" : "=v"(v32));
   asm ("v_mov_b32 %0, %1" : "=v"(vmp) : "s"(mprime));
   const u32 own = (tid == 0 || tid >= (FK_WIN - FK_HR) / FK_UNIT) ? 0u : 0xFFFFFFFFu;   // halo lanes own no tract start
@@ -1337,6 +1360,17 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     else {
       const int ncand = (int) ncand_all;
       const long g0 = tile * (long) FK_OWN - FK_HL;
+      if constexpr (W != 1) {                           // k > 12: two windows per plane (the flanks do not fit one with the tract)
+        for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
+          const int ci = cb0 + tid;
+          bool have = false;
+          u64 c0 = 0, c1 = 0;
+          u32 base = 0, len10 = 0, flag = 0;
+          if (ci < ncand) have = fast_tract<false> (T, seq, n_bytes, g0, (int) T.cand[ci], k, mprime, c0, c1, base, len10, flag);
+          sink.put (have, c0, c1, base, len10, flag, 0ull, (u32) min (ncand - cb0, FK_BLOCK));
+        }
+      }
+      else
       for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
         const int ci = cb0 + tid;
         bool ok = false, general = false;
@@ -1374,7 +1408,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
         if (ok) asm volatile ("" :: "v"(lo), "v"(hi));
 #else
-        sink.put1 (ok, lo, hi, (u32) min (ncand - cb0, FK_BLOCK));
+        if constexpr (W == 1) sink.put1 (ok, lo, hi, (u32) min (ncand - cb0, FK_BLOCK));
 #endif
         STAMP (7);
       }
@@ -1686,11 +1720,18 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
 // ---- W = 2 (k <= 28): word 0 of the record is never 0 and leaves bit 63 free, so it doubles as the slot's claim word:
 // compare-and-swap 0 -> (word0 | PENDING), write word 1, then store word0.  A prober that meets its own word0 with
 // PENDING set looks again; with it clear the second word is there to compare.  Same structure as aggregate1_kernel:
-// records in flight per lane, read-first probing (a bucket holds each key many times), a closed table MARKs the free
-// slot at the end of a probe chain so that a key is in the table for all of its records or for none, leftovers go to
-// the second pool, no barrier in the record loop.
-#define AG2_S        4096
-#define AG2_CLOSE_AT 2560                // typical overshoot: a few keys; worst case one per lane (1024): 87 % full
+// records in flight per lane, read-first probing (a bucket holds each key many times), slots in aligned pairs read
+// together (a probe chain is home pair, next pair, ...; a key lives in the first slot of the chain that was free when it
+// arrived), a closed table MARKs the free slot at the end of a probe chain so that a key is in the table for all of its
+// records or for none, leftovers go to the second pool, no barrier in the record loop.  6144 slots (144 KB of LDS with
+// the counters): a bucket of the long-read configuration (4.6 k keys) fits one round, and at the usual 2-3 k keys the
+// home pair settles nine records in ten.
+#define AG2_S        6144
+#define AG2_PAIRS    (AG2_S / 2)
+#ifndef AG2_CLOSE_AT
+#define AG2_CLOSE_AT 2560
+#endif
+                                        // (closing early pays: at 4.6 k keys per bucket -- the long-read configuration -- a table filled to 75 % costs more in probes than the second round costs in traffic)
 #define AG2_R        4                   // records in flight per lane
 #define AG2_VALID    (1ull << 63)        // set in the stored second key word (bits 61-63 of it are not key)
 #define AG2_PENDING  (1ull << 63)
@@ -1754,69 +1795,93 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       const u32 valid = vn;
       fetch (b0 + AG_BLOCK * AG2_R);
       {
-        auto home = [] (u64 a, u64 b) {
+        auto home = [] (u64 a, u64 b) {                 // home pair of a key
           const u64 key1 = b & ~(3ull << 61);
           u32 h = (u32) a ^ __builtin_amdgcn_alignbit ((u32) (a >> 32), (u32) (a >> 32), 19) ^
                   __builtin_amdgcn_alignbit ((u32) key1, (u32) key1, 11) ^ __builtin_amdgcn_alignbit ((u32) (key1 >> 32), (u32) (key1 >> 32), 25);
           h *= 0x9E3779B1u; h ^= h >> 15;
-          return h & (AG2_S - 1);
+          return __umulhi (h, (u32) AG2_PAIRS);
         };
-        // first, every record looks at its home slot (straight-line code: the loads of all records are in flight
-        // together); a published claim word with the record's own valid second word settles it
-        u32 todo = 0;
+        // the two slots of a pair, loaded together (atomic loads keep the LDS address space)
+        auto load_pair = [&] (u32 pair, ulonglong2 &s0, ulonglong2 &s1) {
+          s0.x = __hip_atomic_load ((unsigned long long *) &L.kk[2 * pair].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          s0.y = __hip_atomic_load ((unsigned long long *) &L.kk[2 * pair].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          s1.x = __hip_atomic_load ((unsigned long long *) &L.kk[2 * pair + 1].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          s1.y = __hip_atomic_load ((unsigned long long *) &L.kk[2 * pair + 1].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        // First, every record walks the first pairs of its chain in straight-line code (the loads of all records of a
+        // lane are in flight together): a published claim word with the record's own valid second word settles it, a full
+        // pair of other keys sends it on to the next pair; anything else (a free slot: the key is new; a slot in the
+        // middle of being published) is left to the general loop below, which starts at the pair reached here.
+        u32 todo = 0, look = 0, cur[AG2_R];
 #pragma unroll
         for (int q = 0; q < AG2_R; q++) {
-          const u64 a0 = w[2 * q], a1 = w[2 * q + 1];
-          if (((valid >> q) & 1u) && ((a1 >> 61) & 3ull) != 3ull) {
-            const u32 sl = home (a0, a1);
-            const u64 x = __hip_atomic_load ((unsigned long long *) &L.kk[sl].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const u64 y = __hip_atomic_load ((unsigned long long *) &L.kk[sl].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (x == a0 && y == ((a1 & fmask) | AG2_VALID)) atomicAdd (&L.cnt[2 * sl + ((u32) (a1 >> 62) & 1u)], 1u);
-            else todo |= 1u << q;
-          }
+          cur[q] = 0;
+          if (((valid >> q) & 1u) && ((w[2 * q + 1] >> 61) & 3ull) != 3ull) { look |= 1u << q; cur[q] = home (w[2 * q], w[2 * q + 1]); }
         }
+#pragma unroll
+        for (int pass = 0; pass < 3; pass++) {
+          if (pass && !look) break;
+#pragma unroll
+          for (int q = 0; q < AG2_R; q++)
+            if ((look >> q) & 1u) {
+              const u64 a0 = w[2 * q], a1 = w[2 * q + 1];
+              ulonglong2 s0, s1;
+              load_pair (cur[q], s0, s1);
+              const u64 want = (a1 & fmask) | AG2_VALID;
+              const bool m0 = (s0.x == a0) & (s0.y == want), m1 = (s1.x == a0) & (s1.y == want);
+              if (m0 | m1) { atomicAdd (&L.cnt[2 * (2 * cur[q] + (m0 ? 0u : 1u)) + ((u32) (a1 >> 62) & 1u)], 1u); look &= ~(1u << q); }
+              else {
+                const u64 mine = a0 | AG2_PENDING;
+                // (a slot holding another key: claim word published, not ours -- or ours with a valid second word that differs)
+                const bool o0 = (s0.x != 0ull) & (s0.x != AG2_MARK) & (s0.x != mine) & ((s0.x & AG2_PENDING) == 0ull) & ((s0.x != a0) | ((s0.y & AG2_VALID) != 0ull));
+                const bool o1 = (s1.x != 0ull) & (s1.x != AG2_MARK) & (s1.x != mine) & ((s1.x & AG2_PENDING) == 0ull) & ((s1.x != a0) | ((s1.y & AG2_VALID) != 0ull));
+                if (o0 & o1) cur[q] = (cur[q] + 1u == (u32) AG2_PAIRS) ? 0u : cur[q] + 1u;
+                else { look &= ~(1u << q); todo |= 1u << q; }
+              }
+            }
+        }
+        todo |= look;
         u32 probes = 0;
         u32 r = todo ? (u32) __ffs ((int) todo) - 1u : 0u;
         u64 w0 = (r == 0u) ? w[0] : (r == 1u) ? w[2] : (r == 2u) ? w[4] : w[6];
         u64 w1 = (r == 0u) ? w[1] : (r == 1u) ? w[3] : (r == 2u) ? w[5] : w[7];
-        u32 slot = home (w0, w1);
+        u32 pair = (r == 0u) ? cur[0] : (r == 1u) ? cur[1] : (r == 2u) ? cur[2] : cur[3];
         while (todo) {
           bool adv = false, left = false;
           {
-            const u64 key1 = w1 & fmask;
+            const u64 key1 = w1 & fmask, want = key1 | AG2_VALID;
             const u32 strand = (u32) (w1 >> 62) & 1u;
-            // the claim word and the second key word (stored with its VALID bit; both are zeroed every round) are loaded
-            // together: a published claim word next to a second word that is not valid yet means the two loads straddled
-            // the owner's writes -- look again
-            ulonglong2 v;                                // (two LDS loads in flight together; atomic loads keep the LDS address space)
-            v.x = __hip_atomic_load ((unsigned long long *) &L.kk[slot].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            v.y = __hip_atomic_load ((unsigned long long *) &L.kk[slot].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const u64 a = v.x;
-            if (a == w0) {
-              if (v.y == (key1 | AG2_VALID)) { atomicAdd (&L.cnt[2 * slot + strand], 1u); adv = true; }
-              else if (v.y & AG2_VALID) {
-                if (++probes >= AG2_S) { left = true; adv = true; }
-                else slot = (slot + 1u) & (AG2_S - 1);
-              }
-            }
-            else if (a == AG2_MARK) { left = true; adv = true; }
-            else if (a == 0ull) {                       // the chain ends here: claim the slot, or MARK it if the table is closed
-              const bool closed = __hip_atomic_load (&L.n_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > AG2_CLOSE_AT;
-              const u64 old = atomicCAS ((unsigned long long *) &L.kk[slot].x, 0ull, closed ? AG2_MARK : (unsigned long long) (w0 | AG2_PENDING));
-              if (old == 0ull) {
-                if (closed) left = true;
-                else {                                  // claimed: publish the second word, then the first
-                  __hip_atomic_store ((unsigned long long *) &L.kk[slot].y, (unsigned long long) (key1 | AG2_VALID), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  atomicAdd (&L.n_claimed, 1u);
-                  __hip_atomic_store ((unsigned long long *) &L.kk[slot].x, (unsigned long long) w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  atomicAdd (&L.cnt[2 * slot + strand], 1u);
+            ulonglong2 s0, s1;
+            load_pair (pair, s0, s1);
+            const bool m0 = (s0.x == w0) & (s0.y == want), m1 = (s1.x == w0) & (s1.y == want);
+            // our own claim word still PENDING, or published next to a second word that is not valid yet (the loads
+            // straddled the owner's writes): look at the pair again
+            const bool again = (s0.x == (w0 | AG2_PENDING)) | (s1.x == (w0 | AG2_PENDING)) |
+                               ((s0.x == w0) & !(s0.y & AG2_VALID)) | ((s1.x == w0) & !(s1.y & AG2_VALID));
+            if (m0 | m1) { atomicAdd (&L.cnt[2 * (2 * pair + (m0 ? 0u : 1u)) + strand], 1u); adv = true; }
+            else if (!again) {
+              const bool e0 = (s0.x == 0ull) | (s0.x == AG2_MARK), e1 = (s1.x == 0ull) | (s1.x == AG2_MARK);
+              if (e0 | e1) {                            // the chain ends in this pair
+                const u32 slot = 2 * pair + (e0 ? 0u : 1u);
+                if ((e0 ? s0.x : s1.x) == AG2_MARK) { left = true; adv = true; }
+                else {                                  // claim the slot, or MARK it if the table is closed
+                  const bool closed = __hip_atomic_load (&L.n_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > AG2_CLOSE_AT;
+                  const u64 old = atomicCAS ((unsigned long long *) &L.kk[slot].x, 0ull, closed ? AG2_MARK : (unsigned long long) (w0 | AG2_PENDING));
+                  if (old == 0ull) {
+                    if (closed) left = true;
+                    else {                              // claimed: publish the second word, then the first
+                      __hip_atomic_store ((unsigned long long *) &L.kk[slot].y, (unsigned long long) want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                      atomicAdd (&L.n_claimed, 1u);
+                      __hip_atomic_store ((unsigned long long *) &L.kk[slot].x, (unsigned long long) w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                      atomicAdd (&L.cnt[2 * slot + strand], 1u);
+                    }
+                    adv = true;
+                  }                                     // else somebody else took the slot: look at the pair again
                 }
-                adv = true;
-              }                                         // else somebody else took the slot: look at it again
-            }
-            else if (a != (w0 | AG2_PENDING)) {         // another key (PENDING with our word0: its owner is still writing, look again)
-              if (++probes >= AG2_S) { left = true; adv = true; }
-              else slot = (slot + 1u) & (AG2_S - 1);
+              }
+              else if (++probes >= AG2_PAIRS) { left = true; adv = true; }   // every slot holds another key
+              else pair = (pair + 1u == (u32) AG2_PAIRS) ? 0u : pair + 1u;
             }
           }
           if (left) {
@@ -1833,7 +1898,7 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
               r = (u32) __ffs ((int) todo) - 1u;
               w0 = (r == 1u) ? w[2] : (r == 2u) ? w[4] : w[6];
               w1 = (r == 1u) ? w[3] : (r == 2u) ? w[5] : w[7];
-              slot = home (w0, w1);
+              pair = (r == 1u) ? cur[1] : (r == 2u) ? cur[2] : cur[3];
             }
           }
         }
@@ -3071,7 +3136,7 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
   static const int fwg = getenv ("TATAJUBA_AMD_FGRID") ? atoi (getenv ("TATAJUBA_AMD_FGRID")) : FK_WG_PER_CU;     // (experiment hook: workgroups per CU)
   const int fgrid = (int) std::min<long> (n_ftiles, (long) c->n_cu * fwg);
   const int lgrid = (int) std::min<long> (n_ftiles * ((FK_OWN + TJ_SB_TILE - 1) / TJ_SB_TILE), (long) c->n_cu * TJ_SB_WG_PER_CU);
-  if (!rc && c->W == 1 && c->fast_mode) rc = ensure (c->slow, (size_t) n_ftiles * 4 + 64, c->stream);
+  if (!rc && c->fast_mode) rc = ensure (c->slow, (size_t) n_ftiles * 4 + 64, c->stream);
   if (rc) return rc;
   const uint8_t *seq = (const uint8_t *) d_stream;
   const Buckets BK = make_buckets (c);
@@ -3079,27 +3144,23 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
   const int par = (int) (c->scan_seq++ & 1u);            // per-launch counters are double-buffered (DevCounters::lc)
   if (first) HIPCHK (hipEventRecord (c->ev_s0, c->stream));
   const TileSrc plain = {nullptr, 0};
+#define TJ_LAUNCH_SCAN(WW) do { \
+    if (c->fast_mode) { \
+      /* the fast kernel takes every tile it can vouch for and lists the others; the generic kernel then works through the list */ \
+      hipLaunchKernelGGL (scan_fast_kernel<WW>, dim3 (fgrid), dim3 (FK_BLOCK), 0, c->stream, seq, (long) n_bytes, n_ftiles, c->k, mprime, BK, c->d_ctr, \
+                          (u32 *) c->slow.p, par, c->fast_mode == 2 ? 1 : 0); \
+      const TileSrc listed = {(const u32 *) c->slow.p, (long) FK_OWN}; \
+      hipLaunchKernelGGL (scan_bins_kernel<WW>, dim3 (lgrid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, 0l, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, listed); \
+    } \
+    else hipLaunchKernelGGL (scan_bins_kernel<WW>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, plain); \
+    hipLaunchKernelGGL (nrun_fixup_bins_kernel<WW>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par); \
+  } while (0)
   switch (c->W) {
-    case 1:
-      if (c->fast_mode) {
-        // the fast kernel takes every tile it can vouch for and lists the others; the generic kernel then works through the list
-        hipLaunchKernelGGL (scan_fast_kernel<1>, dim3 (fgrid), dim3 (FK_BLOCK), 0, c->stream, seq, (long) n_bytes, n_ftiles, c->k, mprime, BK, c->d_ctr,
-                            (u32 *) c->slow.p, par, c->fast_mode == 2 ? 1 : 0);
-        const TileSrc listed = {(const u32 *) c->slow.p, (long) FK_OWN};
-        hipLaunchKernelGGL (scan_bins_kernel<1>, dim3 (lgrid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, 0l, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, listed);
-      }
-      else hipLaunchKernelGGL (scan_bins_kernel<1>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, plain);
-      hipLaunchKernelGGL (nrun_fixup_bins_kernel<1>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par);
-      break;
-    case 2:
-      hipLaunchKernelGGL (scan_bins_kernel<2>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, plain);
-      hipLaunchKernelGGL (nrun_fixup_bins_kernel<2>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par);
-      break;
-    default:
-      hipLaunchKernelGGL (scan_bins_kernel<4>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, plain);
-      hipLaunchKernelGGL (nrun_fixup_bins_kernel<4>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par);
-      break;
+    case 1: TJ_LAUNCH_SCAN (1); break;
+    case 2: TJ_LAUNCH_SCAN (2); break;
+    default: TJ_LAUNCH_SCAN (4); break;
   }
+#undef TJ_LAUNCH_SCAN
   HIPCHK (hipGetLastError ());
   if (last) HIPCHK (hipEventRecord (c->ev_s1, c->stream));
   c->scan_timed = true;

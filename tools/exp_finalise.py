@@ -1,20 +1,10 @@
-"""Diagnostic: scan + finalise of the bench sample with an experimental library build (TJ_DIAG_LIB); prints stage times."""
-import os, sys
+"""Diagnostic: time the finalise of library builds (LIBS="a.so b.so") on one workload (bench.py arguments after --)."""
+import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import tatajuba_amd.build as B
-B._SO = os.path.join(ROOT, "tatajuba_amd", os.environ.get("TJ_DIAG_LIB", "libtatajuba_amd.so"))
-import tatajuba_amd.capi as capi
-capi.library_path = lambda: B._SO
-import tatajuba_amd as tj
-import torch
-s = tj.synth_stream(10_000_000, 150, 5_000_000, n_threads=16)
-d = torch.from_numpy(s).cuda()
-c = tj.Counter(int(os.environ.get("TJ_K", "10")))
-for it in range(4):
-    c.reset(); c.scan_device(d.data_ptr(), s.size, int(os.environ.get("TJ_M", "3")))
-    try:
-        c.finalise(True, 5)
-    except Exception as e:
-        pass
-print(os.environ.get("TJ_DIAG_LIB"), "scan ms %.3f finalise ms %.3f" % (c.last_scan_ms(), c.last_finalise_ms()))
+args = sys.argv[1:]
+for lib in os.environ.get("LIBS", "libtatajuba_amd.so").split():
+    env = dict(os.environ, TJ_DIAG_LIB=lib)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-io-stages", "--no-cpu-baseline"] + args,
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip().splitlines()
+    d = json.loads(out[-1])
+    print(lib, "scan %.3f ms finalise %.3f ms step %.3f ms" % (d["stages"]["scan"]["ms"], d["stages"]["finalise"]["ms"], d["ms_per_step"]))
