@@ -58,6 +58,14 @@ int  tjamd_scan_host (tjamd_counter *c, const void *h_stream, size_t n_bytes, in
 long tjamd_scan_host_located (tjamd_counter *c, const void *h_stream, size_t n_bytes, int min_tract_size,
                               tjamd_located_record *out, long capacity);
 
+/* Many short strings in one launch: what the reference does with one counter and one update_hopo_counter_from_seq call per
+ * reference window (src/genome_set.c:525-577), batched.  seqs[i] / lens[i]: the windows; min_tract_size as in
+ * update_hopo_counter_from_seq (0: the all-monomers scan).  out: hopo_element[capacity] in window order, then read order,
+ * with read_offset relative to the window; window_of[i] (may be NULL) = window of record i.  Uses the calling thread's
+ * shared device context.  Returns the number of records, -1 on error (tjamd_last_error) or if capacity is too small. */
+long tjamd_scan_windows (int kmer_size, const char *const *seqs, const int *lens, int n_windows, int min_tract_size,
+                         hopo_element *out, int *window_of, long capacity);
+
 /* Host-only: parse a FASTA/FASTQ file (plain or gzip; same record semantics as the reference's reader, src/kseq.h:172-212
  * as looped at src/hopo_counter.c:153) into a stream of reads.  Returns the stream's size in bytes and writes it to out
  * when capacity suffices (call with out = NULL to size); *n_reads = records parsed; -1 if the file cannot be opened. */
@@ -75,6 +83,12 @@ long tjamd_read_file_stream_mt (const char *path, unsigned char *out, long capac
 void *tjamd_host_alloc (size_t bytes);
 void tjamd_host_free (void *p);
 int  tjamd_sync (tjamd_counter *c);
+
+/* device memory on the counter's device for callers without HIP headers of their own (buffers for tjamd_merge_samples,
+ * tjamd_tract_ids); tjamd_device_download waits for the counter's stream, then copies to the host */
+void *tjamd_device_alloc (tjamd_counter *c, size_t bytes);
+void tjamd_device_free (tjamd_counter *c, void *p);
+int  tjamd_device_download (tjamd_counter *c, void *host, const void *dev, size_t bytes);
 
 /* Hint: reads of about stream_bytes in total are coming.  Allocates the raw-record storage for them in one piece (up to
  * 4 GB) instead of by repeated growth. */
@@ -107,6 +121,24 @@ const void *tjamd_kept_device_ptr (tjamd_counter *c);   /* tjamd_record[kept_cou
  * out_keys: tjamd_record[n_union] (count field = total), out_counts: int32[n_union * n_samples].  Returns n_union. */
 long tjamd_merge_samples (tjamd_counter *c, const void *d_records, const long *counts, int n_samples,
                           void *d_out_keys, void *d_out_counts, long capacity);
+
+/* The exchange of that merge for a caller that, like the reference, runs its samples as threads of one process
+ * (reference: src/genome_set.c:66-94 OpenMP loop, merge at :195-229): the kept records of the finalised counters
+ * `samples`, whatever devices they live on, copied back to back into a buffer on dst's device (peer copies over xGMI).
+ * counts[i] = records of sample i, *d_records = the buffer (owned by dst until its next gather).  Returns the total. */
+long tjamd_gather_histograms (tjamd_counter *dst, tjamd_counter *const *samples, int n_samples, const void **d_records, long *counts);
+
+/* tract ids on a merged union (reference: src/genome_set.c:207-221, context-keyed: the id goes up wherever
+ * (base, ctx0, ctx1) changes between neighbours of d_keys = tjamd_record[n] in the reference's descending order).
+ * d_tract_id (device, may be NULL) and / or h_tract_id (host, may be NULL) receive int32[n].  Returns the number of ids. */
+long tjamd_tract_ids (tjamd_counter *c, const void *d_keys, long n, int *d_tract_id, int *h_tract_id);
+
+/* within-sample grouping of near-identical contexts on a finalised counter (reference: new_genomic_context_list,
+ * src/context_histogram.c:245-270 with the Hamming distance of :25-48, on the finalised array's own order; no
+ * Levenshtein retry).  group_of: int32[kept_count] (host, may be NULL); groups: one entry per group (host, may be NULL):
+ * first element, elements, distinct contexts, element with the modal count, summed count.  Returns the number of groups. */
+typedef struct { int first, n_elem, n_context, mode; long long integral; } tjamd_group;
+long tjamd_group_contexts (tjamd_counter *c, int max_distance_per_flank, int *group_of, tjamd_group *groups, long capacity);
 
 /* timing of the last operations on this counter, from HIP events on its stream (milliseconds) */
 double tjamd_last_scan_ms (tjamd_counter *c);       /* scan kernel(s) of the last tjamd_scan_* call */

@@ -130,6 +130,16 @@ char *generate_name_from_flanking_contexts (uint64_t *context, int8_t base, int 
 /* reference: src/hopo_counter.c:447-469; caller frees */
 char *generate_tract_as_string (uint64_t *context, int8_t base, int kmer_size, int tract_length, bool neg_strand);
 void print_tatajuba_options (tatajuba_options_t opt);                /* reference: src/hopo_counter.c:115-133 */
+/* distances between packed contexts: differing bases of one flank, counted up to max_dist (reference: src/hopo_counter.h:63,
+ * src/hopo_counter.c:61-68); of both flanks (:64, :70-79); of both flanks allowing one of the two to be shifted by up to
+ * three bases at a cost of one per base, best_shift[4] = bases shifted {c1 left, c2 left, c1 right, c2 right} (:66, :81-113) */
+int distance_between_single_context_kmer (uint64_t *c1, uint64_t *c2, int max_dist);
+int distance_between_context_kmer_pair (uint64_t *c1, uint64_t *c2);
+int distance_between_context_kmer_pair_with_edit_shift (uint64_t *c1, uint64_t *c2, int *best_shift);
+/* reference: src/hopo_counter.h:75, src/hopo_counter.c:188-203; caller frees; NULL (and *tract_length = 0) if the string holds no tract */
+char *leftmost_hopo_name_and_length_from_string (char *seq, size_t len, int kmer_size, int min_tract_size, int *tract_length);
+/* reference: src/hopo_counter.h:77, src/hopo_counter.c:440-445 (obsolete there) */
+int hopo_counter_histogram_integral (hopo_counter hc, int start);
 
 #ifdef __cplusplus
 }

@@ -387,3 +387,122 @@ orc_finalise (orc_counter *oc, int remove_biased, int min_coverage)
   oc->coverage = orc_coverage (oc->elem, oc->n_elem);                                     /* :415 */
   oc->status = 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* "next" rows N3 / N1: distances between packed contexts, greedy grouping of the finalised elements, tract ids.
+ * The reference runs these steps on elements sorted by BWA location (out of scope: the aligner is absent); here, as
+ * in the product, they run on the finalised array in its own (context) order, where read_offset = -1 everywhere so
+ * that the location test of src/context_histogram.c:32-34 always passes.  The Levenshtein retry of
+ * src/context_histogram.c:257-263 (biomcmc_levenshtein_distance, library absent and unpinned) is not restated: an
+ * element that fails the Hamming test opens a new group. */
+
+int
+orc_distance_single (const uint64_t *c1, const uint64_t *c2, int max_dist)
+{ /* reference: src/hopo_counter.c:61-68 */
+  uint64_t d = *c1 ^ *c2;
+  int dist = 0;
+  while (d && (dist < max_dist)) { if (d & 3) dist++; d >>= 2; }
+  return dist;
+}
+
+int
+orc_distance_pair (const uint64_t *c1, const uint64_t *c2)
+{ /* reference: src/hopo_counter.c:70-79 */
+  uint64_t d = c1[0] ^ c2[0];
+  int dist = 0;
+  while (d) { if (d & 3) dist++; d >>= 2; }
+  d = c1[1] ^ c2[1];
+  while (d) { if (d & 3) dist++; d >>= 2; }
+  return dist;
+}
+
+int
+orc_distance_pair_shift (const uint64_t *c1, const uint64_t *c2, int *best_shift)
+{ /* reference: src/hopo_counter.c:81-113 (seven shift pairs per flank, edit cost = bases shifted) */
+  static const int sh[7][3] = {{0,0,0},{0,2,2},{0,4,4},{0,6,6},{2,0,2},{4,0,4},{6,0,6}};
+  int f, i, total = 0;
+  for (f = 0; f < 2; f++) {
+    int best = 0xffffff;
+    for (i = 0; (i < 7) && (best > 0); i++) {
+      int dist = sh[i][2] / 2;
+      uint64_t d = ((c1[f] >> sh[i][0]) ^ (c2[f] >> sh[i][1])) & (~0ULL >> sh[i][2]);
+      while (d) { if (d & 3) dist++; d >>= 2; }
+      if (best > dist) {
+        best = dist;
+        if (best_shift) { best_shift[2 * f] = sh[i][0] / 2; best_shift[2 * f + 1] = sh[i][1] / 2; }
+      }
+    }
+    total += best;
+  }
+  return total;
+}
+
+#define ORC_CH_MAX_DIST 0xffff
+
+static int
+orc_distance_group_elem (const hopo_element *elem, const int *ctx_idx, int n_ctx, int group_base, const hopo_element *he, int max_distance, int *idx_match)
+{ /* reference: src/context_histogram.c:25-48, with the group's contexts given by the elements that introduced them */
+  int i, distance, this_max = 0;
+  *idx_match = -1;
+  if (group_base != he->base) return ORC_CH_MAX_DIST;
+  for (i = 0; i < n_ctx; i++) {
+    const hopo_element *c = &elem[ctx_idx[i]];
+    distance = orc_distance_single (&c->context[0], &he->context[0], 2 * max_distance);
+    if (distance >= 2 * max_distance) return distance;
+    distance += orc_distance_single (&c->context[1], &he->context[1], 2 * max_distance - distance);
+    if (distance >= 2 * max_distance) return distance;
+    if (distance > this_max) this_max = distance;
+    if (distance == 0) { *idx_match = i; return 0; }
+  }
+  return this_max;
+}
+
+/* Greedy grouping of elem[0..n) (reference: new_genomic_context_list, src/context_histogram.c:245-270; bookkeeping of a
+ * group: context_histogram_add_hopo_elem :181-222 and new_context_histogram_from_hopo_elem :140-166).
+ * Outputs, one entry per group: first element, elements, distinct contexts, summed count, element with the modal count
+ * (first one that is larger than all before it).  group_of[i] = group of element i.  Returns the number of groups. */
+long
+orc_group_contexts (const hopo_element *elem, long n, int max_distance_per_flank, int *group_of,
+                    int *g_first, int *g_n_elem, int *g_n_ctx, long *g_integral, int *g_mode)
+{
+  long g = -1, i;
+  int *ctx_idx = (int *) malloc ((size_t) (n > 0 ? n : 1) * sizeof (int));
+  int n_ctx = 0, mode_count = 0, idx_match;
+  for (i = 0; i < n; i++) {
+    int join = 0;
+    if (g >= 0) {
+      int distance = orc_distance_group_elem (elem, ctx_idx, n_ctx, elem[g_first[g]].base, &elem[i], max_distance_per_flank, &idx_match);
+      join = distance < max_distance_per_flank;
+    }
+    if (!join) {                                        /* add_new_context_histogram_from_hopo_elem */
+      g++;
+      g_first[g] = (int) i; g_n_elem[g] = 0; g_integral[g] = 0; g_mode[g] = (int) i;
+      n_ctx = 0; ctx_idx[n_ctx++] = (int) i;
+      mode_count = (int) elem[i].count;
+      g_integral[g] = elem[i].count; g_n_elem[g] = 1;
+    }
+    else {                                              /* context_histogram_add_hopo_elem */
+      if (idx_match < 0) ctx_idx[n_ctx++] = (int) i;
+      if (mode_count < (int) elem[i].count) { mode_count = (int) elem[i].count; g_mode[g] = (int) i; }
+      g_integral[g] += elem[i].count; g_n_elem[g]++;
+    }
+    g_n_ctx[g] = n_ctx;
+    group_of[i] = (int) g;
+  }
+  free (ctx_idx);
+  return g + 1;
+}
+
+/* Tract ids over records in the reference's descending order (reference: src/genome_set.c:207-221 with
+ * context_histograms_overlap() standing for "same location", which in context-keyed form is "same (base, ctx0, ctx1)"):
+ * the id goes up by one wherever the context changes.  Returns the number of ids. */
+long
+orc_tract_ids (const uint64_t *rec3, long n, int *tract_id)
+{
+  long i, id = 0;
+  for (i = 0; i < n; i++) {
+    if (i && (rec3[3 * i] != rec3[3 * (i - 1)] || rec3[3 * i + 1] != rec3[3 * (i - 1) + 1] || ((rec3[3 * i + 2] ^ rec3[3 * (i - 1) + 2]) & 3ULL))) id++;
+    tract_id[i] = (int) id;
+  }
+  return n ? id + 1 : 0;
+}

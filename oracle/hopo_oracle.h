@@ -34,4 +34,14 @@ char *orc_parse_file_to_stream (const char *path, size_t *n_bytes, long *n_reads
 #ifdef __cplusplus
 }
 #endif
+
+/* "next" rows N3 / N1 (see hopo_oracle.c): packed-context distances (reference: src/hopo_counter.c:61-113), greedy grouping
+ * of the finalised elements (src/context_histogram.c:25-48,245-270) and tract ids (src/genome_set.c:207-221), context-keyed */
+int orc_distance_single (const uint64_t *c1, const uint64_t *c2, int max_dist);
+int orc_distance_pair (const uint64_t *c1, const uint64_t *c2);
+int orc_distance_pair_shift (const uint64_t *c1, const uint64_t *c2, int *best_shift);
+long orc_group_contexts (const hopo_element *elem, long n, int max_distance_per_flank, int *group_of,
+                         int *g_first, int *g_n_elem, int *g_n_ctx, long *g_integral, int *g_mode);
+long orc_tract_ids (const uint64_t *rec3, long n, int *tract_id);
+
 #endif

@@ -60,6 +60,13 @@ def lib():
         L.orc_scan_stream.restype = C.c_long
         L.orc_scan_stream.argtypes = [C.POINTER(_OrcCounter), C.c_void_p, C.c_size_t, C.c_int]
         L.orc_finalise.argtypes = [C.POINTER(_OrcCounter), C.c_int, C.c_int]
+        U64P = C.POINTER(C.c_uint64)
+        L.orc_distance_single.argtypes = [U64P, U64P, C.c_int]
+        L.orc_distance_pair.argtypes = [U64P, U64P]
+        L.orc_distance_pair_shift.argtypes = [U64P, U64P, C.POINTER(C.c_int)]
+        L.orc_group_contexts.restype = C.c_long
+        L.orc_group_contexts.argtypes = [C.c_void_p, C.c_long, C.c_int] + [C.c_void_p] * 6
+        L.orc_tract_ids.restype = C.c_long; L.orc_tract_ids.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
         L.orc_parse_file_to_stream.restype = C.c_void_p
         L.orc_parse_file_to_stream.argtypes = [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
         _LIB = L
@@ -142,3 +149,23 @@ def name_of(ctx0, ctx1, base, k):
     left = "".join(dna[(int(ctx0) >> (2 * i)) & 3] for i in range(k))
     right = "".join(dna[(int(ctx1) >> (2 * i)) & 3] for i in range(k))
     return f"{left}.{dna[int(base)]}.{right}"
+
+
+def group_contexts(elems, max_distance_per_flank):
+    """oracle restatement of the reference's greedy grouping on a finalised element array (see hopo_oracle.c)"""
+    e = np.ascontiguousarray(elems)
+    n = len(e)
+    gof = np.zeros(max(n, 1), np.int32)
+    first, nel, nctx, mode = (np.zeros(max(n, 1), np.int32) for _ in range(4))
+    integ = np.zeros(max(n, 1), np.int64)
+    ng = lib().orc_group_contexts(e.ctypes.data, n, max_distance_per_flank, gof.ctypes.data, first.ctypes.data, nel.ctypes.data,
+                                  nctx.ctypes.data, integ.ctypes.data, mode.ctypes.data)
+    return gof[:n], first[:ng], nel[:ng], nctx[:ng], integ[:ng], mode[:ng]
+
+
+def tract_ids(rec3):
+    r = np.ascontiguousarray(rec3)
+    n = len(r)
+    out = np.zeros(max(n, 1), np.int32)
+    nid = lib().orc_tract_ids(r.ctypes.data, n, out.ctypes.data)
+    return out[:n], nid

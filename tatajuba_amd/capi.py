@@ -17,6 +17,7 @@ from .build import build_library, library_path
 ELEM_DTYPE = np.dtype([("ctx0", "<u8"), ("ctx1", "<u8"), ("meta", "<u8"), ("read_offset", "<i4"),
                        ("loc_ref_id", "<i4"), ("loc_pos", "<i4"), ("loc_last", "<i4")])
 RECORD_DTYPE = np.dtype([("ctx0", "<u8"), ("ctx1", "<u8"), ("meta", "<u8")])
+GROUP_DTYPE = np.dtype([("first", "<i4"), ("n_elem", "<i4"), ("n_context", "<i4"), ("mode", "<i4"), ("integral", "<i8")])
 LOCATED_DTYPE = np.dtype([("ctx0", "<u8"), ("ctx1", "<u8"), ("meta", "<u8"), ("pos", "<u8")])
 
 
@@ -76,13 +77,15 @@ EXPORTS = [
     "update_hopo_counter_from_seq_all_monomers",
     "finalise_hopo_counter", "compare_hopo_element_decreasing", "compare_hopo_context",
     "generate_name_from_flanking_contexts", "generate_tract_as_string", "print_tatajuba_options",
+    "distance_between_single_context_kmer", "distance_between_context_kmer_pair", "distance_between_context_kmer_pair_with_edit_shift",
+    "leftmost_hopo_name_and_length_from_string", "hopo_counter_histogram_integral",
     "dna_in_2_bits", "bit_2_dna",
     "tjamd_device_count", "tjamd_last_error", "tjamd_version", "tjamd_counter_create", "tjamd_counter_destroy",
     "tjamd_counter_reset", "tjamd_counter_set_stream", "tjamd_counter_device", "tjamd_scan_device", "tjamd_scan_host",
-    "tjamd_scan_host_located", "tjamd_read_file_stream_mt", "tjamd_host_alloc", "tjamd_host_free", "tjamd_sync", "tjamd_mark", "tjamd_wait_mark", "tjamd_reserve", "tjamd_raw_count",
+    "tjamd_scan_host_located", "tjamd_read_file_stream_mt", "tjamd_host_alloc", "tjamd_host_free", "tjamd_device_alloc", "tjamd_device_free", "tjamd_device_download", "tjamd_sync", "tjamd_mark", "tjamd_wait_mark", "tjamd_reserve", "tjamd_raw_count",
     "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_kept_count",
     "tjamd_n_idx", "tjamd_coverage", "tjamd_download_kept", "tjamd_download_idx", "tjamd_kept_device_ptr",
-    "tjamd_merge_samples", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches",
+    "tjamd_merge_samples", "tjamd_gather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_scan_windows", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches",
     "tjamd_synth_stream", "tjamd_read_file_stream",
 ]
 
@@ -167,6 +170,20 @@ def lib():
     L.tjamd_kept_device_ptr.restype = C.c_void_p; L.tjamd_kept_device_ptr.argtypes = [C.c_void_p]
     L.tjamd_merge_samples.restype = C.c_long
     L.tjamd_merge_samples.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    L.tjamd_gather_histograms.restype = C.c_long
+    L.tjamd_gather_histograms.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_long)]
+    L.tjamd_tract_ids.restype = C.c_long; L.tjamd_tract_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    L.tjamd_group_contexts.restype = C.c_long
+    L.tjamd_group_contexts.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    L.tjamd_scan_windows.restype = C.c_long
+    L.tjamd_scan_windows.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    U64P = C.POINTER(C.c_uint64)
+    L.distance_between_single_context_kmer.argtypes = [U64P, U64P, C.c_int]
+    L.distance_between_context_kmer_pair.argtypes = [U64P, U64P]
+    L.distance_between_context_kmer_pair_with_edit_shift.argtypes = [U64P, U64P, C.POINTER(C.c_int)]
+    L.leftmost_hopo_name_and_length_from_string.restype = C.c_void_p
+    L.leftmost_hopo_name_and_length_from_string.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.hopo_counter_histogram_integral.argtypes = [P, C.c_int]
     L.tjamd_last_scan_ms.restype = C.c_double; L.tjamd_last_scan_ms.argtypes = [C.c_void_p]
     L.tjamd_last_finalise_ms.restype = C.c_double; L.tjamd_last_finalise_ms.argtypes = [C.c_void_p]
     L.tjamd_last_scan_launches.restype = C.c_long; L.tjamd_last_scan_launches.argtypes = [C.c_void_p]
@@ -328,6 +345,14 @@ class Counter:
         a, b = np.zeros(n, np.int32), np.zeros(n, np.int32)
         self._chkn(lib().tjamd_download_idx(self._h, a.ctypes.data, b.ctypes.data, n))
         return a, b
+
+    def group_contexts(self, max_distance_per_flank):
+        """(group_of int32[n_kept], groups structured array) -- tjamd_group_contexts"""
+        n = self.n_kept
+        gof = np.zeros(max(n, 1), dtype=np.int32)
+        grp = np.zeros(max(n, 1), dtype=GROUP_DTYPE)
+        ng = self._chkn(lib().tjamd_group_contexts(self._h, max_distance_per_flank, gof.ctypes.data, grp.ctypes.data, n))
+        return gof[:n], grp[:ng]
 
     def last_scan_launches(self):
         return int(lib().tjamd_last_scan_launches(self._h))

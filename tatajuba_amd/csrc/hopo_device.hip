@@ -810,7 +810,7 @@ __device__ __forceinline__ u32 bucket_of_rec1 (u32 lo, u32 hi)
 
 #define TJ_P        256                 // hash buckets
 #define TJ_PBITS    8
-#define TJ_STAGE_WORDS 4096             // 64-bit words of one-word records a workgroup stages in LDS between partition passes
+#define TJ_STAGE_WORDS 2048             // 64-bit words of one-word records a workgroup stages in LDS between partition passes (twice that in the fast kernel)
 #define TJ_CH0      1536                // chunk size unit in records; chunks are TJ_CH0 << ch_shift with ch_shift >= 2
 #define TJ_EMPTY    0xFFFFFFFFu
 
@@ -891,14 +891,15 @@ __device__ __forceinline__ void bucket_insert_slow (u64 c0, u64 c1, u32 base, u3
 // write every run out contiguously.  All the fixed costs of partitioning (barriers, reservations, chunk look-ups) are
 // paid once per ~4096 records instead of once per tile.
 
-template <int W>
+template <int W, bool BIG = false>
 struct StageLds
 {
   // a staged record is WS words (the 4th word of a W = 4 record is padding and only exists in HBM); the two-word and
   // three-word formats get 21 KB instead of 16: fewer, fuller partition passes (their fixed cost is per pass), still three
   // workgroups per CU
   static constexpr int WS = (W == 4) ? 3 : W;
-  static constexpr int WORDS = (W == 1) ? TJ_STAGE_WORDS : 2688;
+  // (BIG: scan_fast_kernel, two workgroups per CU: twice the records per pass, runs twice as long)
+  static constexpr int WORDS = ((W == 1) ? TJ_STAGE_WORDS : 2688) * (BIG ? 2 : 1);
   static constexpr int S = WORDS / WS;                   // records
   u64 rec[WORDS];
   u64 gbase[TJ_P];                                      // pool index of the first record of the bucket's run
@@ -911,14 +912,14 @@ struct StageLds
   unsigned char bin[S];
 };
 
-template <int W, int BLOCK>
+template <int W, int BLOCK, bool BIG = false>
 struct StageSink
 {
   static constexpr bool K32 = (W == 1);                 // k <= 12: the scan may use 32-bit k-mer arithmetic
-  static constexpr int S = StageLds<W>::S;
-  static constexpr int WS = StageLds<W>::WS;
+  static constexpr int S = StageLds<W, BIG>::S;
+  static constexpr int WS = StageLds<W, BIG>::WS;
   static constexpr int R = (S + BLOCK - 1) / BLOCK;     // staged records per thread in a partition pass
-  StageLds<W> &L;
+  StageLds<W, BIG> &L;
   Buckets B; DevCounters *ctr; int k;
   u32 bound;                                            // upper bound of the records staged (workgroup-uniform)
   u32 cur_j, cur_chunk;                                 // owner thread (tid < TJ_P): the chunk its bucket is being written to
@@ -1219,8 +1220,8 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 {
   __shared__ FastLds T;
   __shared__ uint4 raw[FK_WIN / 16];
-  __shared__ StageLds<W> SL;
-  StageSink<W, FK_BLOCK> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
+  __shared__ StageLds<W, W == 1> SL;
+  StageSink<W, FK_BLOCK, W == 1> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
   sink.start ();
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2962,6 +2963,23 @@ extern "C" void *tjamd_host_alloc (size_t bytes)
 
 extern "C" void tjamd_host_free (void *p) { if (p) (void) hipHostFree (p); }
 
+// device memory for callers that have no HIP headers of their own (outputs of tjamd_merge_samples and the like)
+extern "C" void *tjamd_device_alloc (tjamd_counter *c, size_t bytes)
+{
+  void *p = nullptr;
+  if (!c || hipSetDevice (c->device) != hipSuccess || hipMalloc (&p, bytes ? bytes : 1) != hipSuccess) { set_err (TJAMD_ERR_HIP, "hipMalloc of %zu bytes failed", bytes); return NULL; }
+  return p;
+}
+extern "C" void tjamd_device_free (tjamd_counter *c, void *p) { if (c && p && hipSetDevice (c->device) == hipSuccess) (void) hipFree (p); }
+extern "C" int tjamd_device_download (tjamd_counter *c, void *host, const void *dev, size_t bytes)
+{
+  if (!c || (bytes && (!host || !dev))) return set_err (TJAMD_ERR_ARG, "bad arguments");
+  HIPCHK (hipSetDevice (c->device));
+  HIPCHK (hipStreamSynchronize (c->stream));
+  if (bytes) HIPCHK (hipMemcpy (host, dev, bytes, hipMemcpyDeviceToHost));
+  return TJAMD_OK;
+}
+
 extern "C" int tjamd_sync (tjamd_counter *c)
 {
   if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
@@ -3620,6 +3638,174 @@ extern "C" long tjamd_last_scan_launches (tjamd_counter *c) { return c ? c->last
 
 // radix path of the merge: tag, stable sort, run heads, scans (any size, any skew)
 static long merge_samples_radix (tjamd_counter *c, const void *d_records, long n, int n_samples, void *d_out_keys, void *d_out_counts, long capacity);
+
+// ---------------------------------------------------------------------------------------------------------------
+// "next" rows N3 / N1 on the device: grouping of near-identical contexts within a sample, tract ids on a union.
+//
+// Grouping (reference: new_genomic_context_list, src/context_histogram.c:245-270 with the distance of :25-48): the
+// reference walks the elements in order and lets element i join the group being built iff it has the group's base and
+// is closer than max_distance_per_flank (differing flank bases, both flanks together) to EVERY context already in it;
+// otherwise i starts a new group.  (It walks them in BWA-location order and retries with a Levenshtein distance; here
+// the order is the finalised array's own and there is no retry: the aligner and biomcmc-lib are absent.)
+// On the device: back[i] = nearest j < i that element i could not share a group with (a thread walks back until it
+// meets one); i can join iff the current group started after back[i].  Positions with back[i] == i - 1 start a group
+// whatever came before, so the array falls into independent stretches, each walked by one thread.
+
+__device__ __forceinline__ int flank_hamming (u64 a, u64 b)
+{ // differing 2-bit positions of two packed k-mers (reference: src/hopo_counter.c:61-68 counts them one by one)
+  const u64 d = a ^ b;
+  return __popcll ((d | (d >> 1)) & 0x5555555555555555ull);
+}
+
+__global__ void group_back_kernel (const u64 *__restrict__ kept, long n, int maxd, int *__restrict__ back)
+{
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
+    const u64 c0 = kept[3 * i], c1 = kept[3 * i + 1], base = kept[3 * i + 2] & 3ull;
+    long j = i - 1;
+    while (j >= 0 && (kept[3 * j + 2] & 3ull) == base && flank_hamming (kept[3 * j], c0) + flank_hamming (kept[3 * j + 1], c1) < maxd) j--;
+    back[i] = (int) j;
+  }
+}
+
+__global__ void group_resolve_kernel (const int *__restrict__ back, long n, u32 *__restrict__ head)
+{
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
+    if (back[i] != (int) i - 1) continue;               // (i == 0: back = -1) only stretch starts walk
+    head[i] = 1u;
+    long start = i;
+    for (long j = i + 1; j < n && back[j] != (int) j - 1; j++) {
+      if (start > (long) back[j]) head[j] = 0u;
+      else { head[j] = 1u; start = j; }
+    }
+  }
+}
+
+struct GroupOut { int first, n_elem, n_context, mode; long long integral; };
+
+__global__ void group_summary_kernel (const u64 *__restrict__ kept, long n, const u32 *__restrict__ head, const u32 *__restrict__ gid_excl,
+                                      int *__restrict__ group_of, GroupOut *__restrict__ groups)
+{
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
+    if (!head[i]) continue;
+    const int g = (int) gid_excl[i];                     // groups before this head
+    GroupOut o = {(int) i, 0, 0, (int) i, 0};
+    int mode_count = 0;
+    for (long j = i; j < n && (j == i || !head[j]); j++) {   // (reference: context_histogram_add_hopo_elem, src/context_histogram.c:181-222)
+      const u64 m = kept[3 * j + 2];
+      int cnt = (int) ((m >> TJ_META_COUNT_SHIFT) & 0xFFFFFull);
+      if (cnt & 0x80000) cnt -= 0x100000;               // signed 20-bit field
+      if (j == i || kept[3 * j] != kept[3 * (j - 1)] || kept[3 * j + 1] != kept[3 * (j - 1) + 1]) o.n_context++;
+      if (j == i || mode_count < cnt) { mode_count = cnt; o.mode = (int) j; }
+      o.integral += cnt; o.n_elem++;
+      group_of[j] = g;
+    }
+    groups[g] = o;
+  }
+}
+
+extern "C" long tjamd_group_contexts (tjamd_counter *c, int max_distance_per_flank, int *group_of, tjamd_group *groups, long capacity)
+{
+  if (!c || max_distance_per_flank < 0) return -set_err (TJAMD_ERR_ARG, "bad arguments");
+  if (c->status < 0) return -set_err (TJAMD_ERR_STATE, "tjamd_group_contexts needs a finalised counter");
+  if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
+  const long n = c->n_kept;
+  if (n == 0) return 0;
+  static_assert (sizeof (GroupOut) == sizeof (tjamd_group), "group layout");
+  int rc = ensure (c->headpos, (size_t) n * 4, c->stream);          // back[]
+  if (!rc) rc = ensure (c->flags, (size_t) n * 4, c->stream);      // head flags
+  if (!rc) rc = ensure (c->outpos, (size_t) n * 4, c->stream);     // groups before each element
+  if (!rc) rc = ensure (c->segid, (size_t) n * 4, c->stream);      // group_of
+  if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n) * 4 + 64, c->stream);
+  if (!rc) rc = ensure (c->alt, (size_t) n * sizeof (GroupOut), c->stream);
+  if (rc) return -rc;
+  const u64 *kept = (const u64 *) c->kept.p;
+  u32 *total = (u32 *) c->scan_tmp.p + scan_tmp_words (n);
+  hipLaunchKernelGGL (group_back_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, kept, n, max_distance_per_flank, (int *) c->headpos.p);
+  hipLaunchKernelGGL (group_resolve_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const int *) c->headpos.p, n, (u32 *) c->flags.p);
+  rc = exclusive_scan (c, (const u32 *) c->flags.p, (u32 *) c->outpos.p, n, total, (u32 *) c->scan_tmp.p, scan_tmp_words (n));
+  if (rc) return -rc;
+  hipLaunchKernelGGL (group_summary_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, kept, n, (const u32 *) c->flags.p, (const u32 *) c->outpos.p,
+                      (int *) c->segid.p, (GroupOut *) c->alt.p);
+  if (hipGetLastError () != hipSuccess) return -set_err (TJAMD_ERR_HIP, "grouping launch failed");
+  u32 ng = 0;
+  if (hipMemcpyAsync (&ng, total, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize (c->stream) != hipSuccess)
+    return -set_err (TJAMD_ERR_HIP, "grouping failed: %s", hipGetErrorString (hipGetLastError ()));
+  if ((long) ng > capacity && groups) return -set_err (TJAMD_ERR_CAPACITY, "%u groups, caller capacity %ld", ng, capacity);
+  if (group_of && hipMemcpy (group_of, c->segid.p, (size_t) n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  if (groups && hipMemcpy (groups, c->alt.p, (size_t) ng * sizeof (GroupOut), hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  return (long) ng;
+}
+
+// Tract ids on a merged union (reference: src/genome_set.c:207-221: the id goes up wherever two neighbours of the
+// concatenated list do not overlap; context-keyed: wherever (base, ctx0, ctx1) changes).  d_keys: tjamd_record[n] in the
+// reference's descending order, as tjamd_merge_samples writes them.
+__global__ void tract_head_kernel (const u64 *__restrict__ keys, long n, u32 *__restrict__ head)
+{
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x)
+    head[i] = (i > 0 && (keys[3 * i] != keys[3 * (i - 1)] || keys[3 * i + 1] != keys[3 * (i - 1) + 1] || ((keys[3 * i + 2] ^ keys[3 * (i - 1) + 2]) & 3ull))) ? 1u : 0u;
+}
+__global__ void tract_id_kernel (const u32 *__restrict__ excl, const u32 *__restrict__ head, long n, int *__restrict__ id)
+{
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) id[i] = (int) (excl[i] + head[i]);
+}
+
+extern "C" long tjamd_tract_ids (tjamd_counter *c, const void *d_keys, long n, int *d_tract_id, int *h_tract_id)
+{
+  if (!c || n < 0 || (n && !d_keys)) return -set_err (TJAMD_ERR_ARG, "bad arguments");
+  if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
+  if (n == 0) return 0;
+  int rc = ensure (c->flags, (size_t) n * 4, c->stream);
+  if (!rc) rc = ensure (c->outpos, (size_t) n * 4, c->stream);
+  if (!rc) rc = ensure (c->segid, (size_t) n * 4, c->stream);
+  if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n) * 4 + 64, c->stream);
+  if (rc) return -rc;
+  u32 *total = (u32 *) c->scan_tmp.p + scan_tmp_words (n);
+  int *ids = d_tract_id ? d_tract_id : (int *) c->segid.p;
+  hipLaunchKernelGGL (tract_head_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) d_keys, n, (u32 *) c->flags.p);
+  rc = exclusive_scan (c, (const u32 *) c->flags.p, (u32 *) c->outpos.p, n, total, (u32 *) c->scan_tmp.p, scan_tmp_words (n));
+  if (rc) return -rc;
+  hipLaunchKernelGGL (tract_id_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u32 *) c->outpos.p, (const u32 *) c->flags.p, n, ids);
+  if (hipGetLastError () != hipSuccess) return -set_err (TJAMD_ERR_HIP, "tract id launch failed");
+  u32 nh = 0;
+  if (hipMemcpyAsync (&nh, total, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize (c->stream) != hipSuccess)
+    return -set_err (TJAMD_ERR_HIP, "tract ids failed: %s", hipGetErrorString (hipGetLastError ()));
+  if (h_tract_id && hipMemcpy (h_tract_id, ids, (size_t) n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  return (long) nh + 1;
+}
+
+// The exchange of the cross-sample merge for a caller that, like the reference, runs its samples as threads of ONE
+// process (src/genome_set.c:66-94; merge at :195-229): the kept records of the finalised counters `samples` -- each on
+// the device its thread bound it to -- are copied into one buffer on dst's device (peer copies over xGMI between
+// devices, a plain device copy on the same one), back to back in sample order.  counts[i] = records of sample i;
+// *d_records = the buffer (owned by dst, valid until its next gather).  Returns the total, ready for
+// tjamd_merge_samples (dst, *d_records, counts, n_samples, ...).
+extern "C" long tjamd_gather_histograms (tjamd_counter *dst, tjamd_counter *const *samples, int n_samples, const void **d_records, long *counts)
+{
+  if (!dst || !samples || n_samples < 1 || !d_records || !counts) return -set_err (TJAMD_ERR_ARG, "bad arguments");
+  long n = 0;
+  for (int i = 0; i < n_samples; i++) {
+    if (!samples[i] || samples[i]->status < 0) return -set_err (TJAMD_ERR_STATE, "sample %d is not finalised", i);
+    counts[i] = samples[i]->n_kept; n += counts[i];
+  }
+  if (hipSetDevice (dst->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
+  int rc = ensure (dst->rawlist, (size_t) std::max<long> (n, 1) * 24, dst->stream);
+  if (rc) return -rc;
+  size_t off = 0;
+  for (int i = 0; i < n_samples; i++) {
+    const size_t bytes = (size_t) counts[i] * 24;
+    if (!bytes) continue;
+    tjamd_counter *s = samples[i];
+    hipError_t e = (s->device == dst->device)
+      ? hipMemcpyAsync ((char *) dst->rawlist.p + off, s->kept.p, bytes, hipMemcpyDeviceToDevice, dst->stream)
+      : hipMemcpyPeerAsync ((char *) dst->rawlist.p + off, dst->device, s->kept.p, s->device, bytes, dst->stream);
+    if (e != hipSuccess) return -set_err (TJAMD_ERR_HIP, "gather copy of sample %d failed: %s", i, hipGetErrorString (e));
+    off += bytes;
+  }
+  if (hipStreamSynchronize (dst->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "gather failed");
+  *d_records = dst->rawlist.p;
+  return n;
+}
+
 
 extern "C" long tjamd_merge_samples (tjamd_counter *c, const void *d_records, const long *counts, int n_samples,
                                       void *d_out_keys, void *d_out_counts, long capacity)

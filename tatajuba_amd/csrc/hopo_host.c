@@ -326,6 +326,30 @@ update_hopo_counter_from_seq_all_monomers (hopo_counter hc, char *seq, int seq_l
   tj_scan_seq (hc, seq, seq_length, 0);
 }
 
+/* Device context for the synchronous string scans.  The reference creates a counter per reference window
+ * (src/genome_set.c:530-555: thousands of them); giving each its own stream, events and device buffers would cost
+ * more than the scans.  They share one context per calling thread and k-mer size, bound to the device that thread's
+ * first counter was given (counters that scan files keep a context of their own: tj_device_counter). */
+#define TJ_SCRATCH_SLOTS 4
+static __thread struct { int k; tjamd_counter *dev; } tj_scratch[TJ_SCRATCH_SLOTS];
+
+static tjamd_counter *
+tj_scratch_counter (int kmer_size)
+{
+  int i, n, dev;
+  const char *pin = getenv ("TATAJUBA_AMD_DEVICE");
+  for (i = 0; i < TJ_SCRATCH_SLOTS; i++) if (tj_scratch[i].dev && tj_scratch[i].k == kmer_size) return tj_scratch[i].dev;
+  n = tjamd_device_count ();
+  if (n <= 0) tj_fatal ("no HIP device is visible; the homopolymer scan runs on an MI355X only (there is no CPU fallback)");
+  dev = pin ? atoi (pin) : (__atomic_fetch_add (&tj_next_device, 1, __ATOMIC_RELAXED) % n);
+  for (i = 0; i < TJ_SCRATCH_SLOTS && tj_scratch[i].dev; i++) ;
+  if (i == TJ_SCRATCH_SLOTS) { tjamd_counter_destroy (tj_scratch[0].dev); i = 0; }      /* (more than four k-mer sizes in one thread: recycle) */
+  tj_scratch[i].k = kmer_size;
+  tj_scratch[i].dev = tjamd_counter_create (dev, kmer_size);
+  if (!tj_scratch[i].dev) tj_fatal ("%s", tjamd_last_error ());
+  return tj_scratch[i].dev;
+}
+
 static void
 tj_scan_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size)
 {
@@ -336,7 +360,7 @@ tj_scan_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size)
   long i, n, cap;
 
   if (seq_length <= hc->kmer_size) return;              /* reference loop bound :226 */
-  dev = tj_device_counter (hc);
+  dev = pv->dev ? pv->dev : tj_scratch_counter (hc->kmer_size);
   cap = (min_tract_size ? seq_length / 2 : seq_length) + 2;
   stream = (unsigned char *) malloc ((size_t) seq_length + 1);
   rec = (tjamd_located_record *) malloc ((size_t) cap * sizeof (tjamd_located_record));
@@ -462,6 +486,114 @@ generate_name_from_flanking_contexts (uint64_t *context, int8_t base, int kmer_s
   s[2 * kmer_size + 3] = '\0';
   free (t);
   return s;
+}
+
+/* ---- distances between packed contexts (reference: src/hopo_counter.c:61-113; callers: src/context_histogram.c) ---- */
+
+static int
+tj_mismatches (uint64_t d, int dist, int stop)
+{ /* bases (2-bit groups) in which d is non-zero, added to dist, counting no further than `stop` */
+  for (; d && dist < stop; d >>= 2) dist += (d & 3) != 0;
+  return dist;
+}
+
+int
+distance_between_single_context_kmer (uint64_t *c1, uint64_t *c2, int max_dist)
+{ /* reference :61-68: never more than max_dist */
+  return tj_mismatches (*c1 ^ *c2, 0, max_dist);
+}
+
+int
+distance_between_context_kmer_pair (uint64_t *c1, uint64_t *c2)
+{ /* reference :70-79: both flanks, uncapped */
+  return tj_mismatches (c1[1] ^ c2[1], tj_mismatches (c1[0] ^ c2[0], 0, 65), 130);
+}
+
+int
+distance_between_context_kmer_pair_with_edit_shift (uint64_t *c1, uint64_t *c2, int *best_shift)
+{ /* reference :81-113: per flank, the cheapest of "no shift", c2 shifted by 1-3 bases, c1 shifted by 1-3 bases (a shift
+   * of s bases costs s and drops the s top bases from the comparison); tried in that order, first minimum wins,
+   * a zero ends the search */
+  int f, total = 0;
+  for (f = 0; f < 2; f++) {
+    int best = 0xffffff, t;
+    for (t = 0; t < 7 && best > 0; t++) {
+      const int s = (t <= 3) ? t : t - 3, s1 = (t <= 3) ? 0 : s, s2 = (t <= 3) ? s : 0;
+      const int dist = tj_mismatches (((c1[f] >> (2 * s1)) ^ (c2[f] >> (2 * s2))) & (~0ULL >> (2 * s)), s, 1000);
+      if (dist < best) {
+        best = dist;
+        if (best_shift) { best_shift[2 * f] = s1; best_shift[2 * f + 1] = s2; }
+      }
+    }
+    total += best;
+  }
+  return total;
+}
+
+/* reference: src/hopo_counter.c:188-203: name of the first tract of a (reference) string, NULL and length 0 if none */
+char *
+leftmost_hopo_name_and_length_from_string (char *seq, size_t len, int kmer_size, int min_tract_size, int *tract_length)
+{
+  hopo_counter hc = new_hopo_counter (kmer_size);
+  char *name = NULL;
+  update_hopo_counter_from_seq (hc, seq, (int) len, min_tract_size);
+  *tract_length = 0;
+  if (hc->n_elem) {
+    *tract_length = hc->elem[0].length;
+    name = generate_name_from_flanking_contexts (hc->elem[0].context, (int8_t) hc->elem[0].base, kmer_size, false);
+  }
+  del_hopo_counter (hc);
+  return name;
+}
+
+/* reference: src/hopo_counter.c:440-445 (marked obsolete there): depth of the start-th indexed context */
+int
+hopo_counter_histogram_integral (hopo_counter hc, int start)
+{
+  int i, depth = 0;
+  for (i = hc->idx_initial[start]; i < hc->idx_final[start]; i++) depth += hc->elem[i].count;
+  return depth;
+}
+
+/* ---- many short strings at once (the reference's per-tract rescans, src/genome_set.c:525-577) ----------------------
+ * One stream, one launch, one synchronisation for all windows instead of a device round trip per window.  Records come
+ * back in window order, then in read order; read_offset is relative to the window (start of the left flank, as in
+ * update_hopo_counter_from_seq).  window_of[i] = window of record i.  Returns the number of records, -1 on error. */
+long
+tjamd_scan_windows (int kmer_size, const char *const *seqs, const int *lens, int n_windows, int min_tract_size,
+                    hopo_element *out, int *window_of, long capacity)
+{
+  tjamd_counter *dev;
+  tjamd_located_record *rec;
+  unsigned char *stream;
+  long *start;
+  long total = 0, n, i, cap, w = 0;
+  if (n_windows < 0 || (n_windows && (!seqs || !lens))) return -1;
+  start = (long *) malloc (((size_t) n_windows + 1) * sizeof (long));
+  for (i = 0; i < n_windows; i++) { start[i] = total; total += (lens[i] > 0 ? lens[i] : 0) + 1; }
+  start[n_windows] = total;
+  if (!total) { free (start); return 0; }
+  stream = (unsigned char *) malloc ((size_t) total);
+  for (i = 0; i < n_windows; i++) {
+    if (lens[i] > 0) memcpy (stream + start[i], seqs[i], (size_t) lens[i]);
+    stream[start[i + 1] - 1] = '\n';
+  }
+  cap = (min_tract_size ? total / 2 : total) + 2;
+  rec = (tjamd_located_record *) malloc ((size_t) cap * sizeof (tjamd_located_record));
+  dev = tj_scratch_counter (kmer_size);
+  n = tjamd_scan_host_located (dev, stream, (size_t) total, min_tract_size, rec, cap);
+  if (n > capacity) n = -1;
+  for (i = 0; i < n; i++) {
+    hopo_element *e = out + i;
+    while ((long) rec[i].pos >= start[w + 1]) w++;      /* records come sorted by position */
+    e->context[0] = rec[i].ctx0; e->context[1] = rec[i].ctx1;
+    memcpy ((char *) e + 16, &rec[i].meta, 8);
+    e->read_offset = (int32_t) ((long) rec[i].pos - start[w] - kmer_size);
+    e->loc_ref_id = e->loc_pos = e->loc_last = -1;
+    if (window_of) window_of[i] = (int) w;
+  }
+  free (rec); free (stream); free (start);
+  return n;
 }
 
 void

@@ -4,6 +4,7 @@ device entries fail loudly without a GPU.  No compute call is made here."""
 import ctypes as C
 import gzip
 import os
+import random
 import re
 
 import numpy as np
@@ -288,3 +289,59 @@ def test_c_example_links_and_fails_loudly_without_gpu(tmp_path, golden_dir):
         pytest.skip("a GPU is visible: covered by the gpu test")
     r = subprocess.run([exe, os.path.join(golden_dir, "err1750956.fastq.gz"), "-k", "10", "-m", "3"], capture_output=True, text=True)
     assert r.returncode == 1 and "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
+
+
+# ---- host helpers of the reference header that need no GPU: distances between packed contexts (src/hopo_counter.c:61-113)
+
+def _u64pair(a, b):
+    import ctypes as C
+    return (C.c_uint64 * 2)(a, b)
+
+
+def test_context_distances_match_the_oracle():
+    import ctypes as C
+    L, O = tj.lib(), orc.lib()
+    rng = random.Random(11)
+    for it in range(4000):
+        k = rng.choice([3, 10, 15, 25, 32])
+        mask = (1 << (2 * k)) - 1
+        a = [rng.getrandbits(64) & mask, rng.getrandbits(64) & mask]
+        b = list(a)
+        for _ in range(rng.choice([0, 0, 1, 2, 3, 8])):      # a few substitutions
+            f, pos = rng.randrange(2), rng.randrange(k)
+            b[f] ^= rng.randrange(1, 4) << (2 * pos)
+        if rng.random() < 0.3:                               # or a shifted copy (what the edit-shift distance is for)
+            f, sft = rng.randrange(2), 2 * rng.randrange(1, 4)
+            b[f] = (a[f] >> sft) if rng.random() < 0.5 else ((a[f] << sft) & mask)
+        pa, pb = _u64pair(*a), _u64pair(*b)
+        assert L.distance_between_context_kmer_pair(pa, pb) == O.orc_distance_pair(pa, pb)
+        for md in (1, 2, 5, 64):
+            assert L.distance_between_single_context_kmer(pa, pb, md) == O.orc_distance_single(pa, pb, md)
+        s1, s2 = (C.c_int * 4)(9, 9, 9, 9), (C.c_int * 4)(9, 9, 9, 9)
+        assert L.distance_between_context_kmer_pair_with_edit_shift(pa, pb, s1) == O.orc_distance_pair_shift(pa, pb, s2)
+        assert list(s1) == list(s2)
+    # by hand: CCG|GAT vs CCA|GAT differ in one base; a flank shifted by one base costs 1
+    ccg, gat, cca = 0x25, 0x32, 0x05
+    assert L.distance_between_context_kmer_pair(_u64pair(ccg, gat), _u64pair(cca, gat)) == 1
+    sh = (C.c_int * 4)()
+    assert L.distance_between_context_kmer_pair_with_edit_shift(_u64pair(ccg, gat), _u64pair(ccg >> 2, gat), sh) == 1 and list(sh) == [1, 0, 0, 0]
+
+
+def test_oracle_grouping_by_hand():
+    """greedy grouping of a finalised array (reference: src/context_histogram.c:245-270): an element joins the group being
+    built iff it is closer than max_distance_per_flank to every context in it"""
+    e = np.zeros(6, dtype=tj.ELEM_DTYPE)
+    ctx = [(0x25, 0x32), (0x25, 0x32), (0x24, 0x32), (0x14, 0x32), (0x14, 0x12), (0x00, 0x00)]     # 1 - 2: 1 apart; 2 - 3: 1; 1 - 3: 2
+    cnt = [5, 9, 4, 7, 2, 3]
+    for i, ((a, b), c) in enumerate(zip(ctx, cnt)):
+        e["ctx0"][i], e["ctx1"][i] = a, b
+        e["meta"][i] = (4 << 2) | (c << 12)                # base A, length 4
+    gof, first, nel, nctx, integ, mode = orc.group_contexts(e, 1)
+    assert gof.tolist() == [0, 0, 1, 2, 3, 4]              # distance must be < 1: identical contexts only
+    gof, first, nel, nctx, integ, mode = orc.group_contexts(e, 2)
+    assert gof.tolist() == [0, 0, 0, 1, 1, 2]              # the 4th is 2 away from the first context of group 0
+    assert nel.tolist() == [3, 2, 1] and nctx.tolist() == [2, 2, 1] and integ.tolist() == [18, 9, 3] and mode.tolist() == [1, 3, 5]
+    rec = np.zeros((5, 3), np.uint64)
+    rec[:, 0] = [9, 9, 9, 7, 7]; rec[:, 1] = [4, 4, 3, 3, 3]; rec[:, 2] = [1, 1, 1, 1, 0]
+    ids, n = orc.tract_ids(rec)
+    assert ids.tolist() == [0, 0, 1, 2, 3] and n == 4

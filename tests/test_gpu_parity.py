@@ -635,3 +635,211 @@ def test_full_size_properties_config2():
     assert c.raw_count() == raw and c.finalise(1, 5) == 0
     assert c.download_kept().tobytes() == kept.tobytes() and c.coverage == cov
     c.close()
+
+
+def _sorted_desc(kept, d):
+    key = np.stack([d["base"].astype(np.uint64), kept["ctx0"], kept["ctx1"], d["length"].astype(np.uint64)], 1)
+    a, b = key[:-1], key[1:]
+    gt = np.zeros(len(a), bool)
+    eq = np.ones(len(a), bool)
+    for j in range(4):
+        gt |= eq & (a[:, j] > b[:, j])
+        eq &= a[:, j] == b[:, j]
+    return bool(gt.all())
+
+
+def test_full_size_properties_config3():
+    """BASELINE config 3's parameters (150 bp reads, 50 Mb genome, k=15 m=4, strand-bias filter) on a 3 GB stream: the scan
+    runs in the library's real 1 GiB pieces (three launches, cuts on read delimiters), two-word records, and the result
+    has the properties that need no CPU pass at this size; a 1/16 sample agrees with the oracle exactly."""
+    n_reads, L, k, m = 20_000_000, 150, 15, 4
+    s = tj.synth_stream(n_reads, L, 50_000_000, n_threads=16)
+    assert s.size > (3 << 30) // 2                              # more than 1.5 GiB: scanned piece by piece
+    c = tj.Counter(k)
+    c.scan_host(s, m)
+    assert c.last_scan_launches() >= 3
+    raw = c.raw_count()
+    assert 1.25 < raw / n_reads < 1.5                           # r-bar ~ 1.37 (SURVEY 8a)
+    assert c.finalise(1, 5) == 0
+    kept = c.download_kept()
+    d = tj.decode_meta(kept["meta"])
+    assert _sorted_desc(kept, d)
+    assert (d["canon_flag"] == 3).all() and (d["count"] >= 2).all() and int(d["count"].sum()) <= raw
+    gi, gf = c.download_idx()
+    assert (gi < gf).all() and (gf[:-1] <= gi[1:]).all() and gf[-1] <= len(kept)
+    cov = c.coverage
+    check_finalise([s[: (n_reads // 16) * (L + 1)]], k, m, 1, 5)
+    # strand symmetry: reverse-complementing every read gives the same histogram
+    c.reset()
+    c.scan_host(_revcomp_stream(s, L), m)
+    assert c.raw_count() == raw and c.finalise(1, 5) == 0
+    assert c.download_kept().tobytes() == kept.tobytes() and c.coverage == cov
+    c.close()
+
+
+def test_full_size_properties_config5():
+    """BASELINE config 5's parameters (reads of 2-20 kb, 100 Mb genome, k=25 m=4) on 1.1 GB of ragged long reads: raw
+    record density, order, filter and index properties; a 1/16 sample agrees with the oracle exactly; linearity."""
+    n_reads, k, m = 100_000, 25, 4
+    s = tj.synth_stream(n_reads, 2000, 100_000_000, read_len_max=20000, n_threads=16)
+    assert s.size > 1_000_000_000
+    c = tj.Counter(k)
+    c.scan_host(s, m)
+    raw = c.raw_count()
+    assert 0.0105 < raw / s.size < 0.0125                       # 0.0117 tracts per base (SURVEY 8d)
+    st = c.finalise(1, 2)
+    assert st == 0
+    kept = c.download_kept()
+    d = tj.decode_meta(kept["meta"])
+    assert _sorted_desc(kept, d)
+    assert (d["canon_flag"] == 3).all() and (d["count"] >= 2).all() and int(d["count"].sum()) <= raw
+    gi, gf = c.download_idx()
+    assert (gi < gf).all() and (gf[:-1] <= gi[1:]).all() and gf[-1] <= len(kept)
+    cov = c.coverage
+    ends = np.flatnonzero(s[: s.size // 16] == 10)
+    check_finalise([s[: ends[-1] + 1]], k, m, 1, 2)
+    c.reset()
+    c.scan_host(s, m); c.scan_host(s, m)
+    assert c.raw_count() == 2 * raw and c.finalise(1, 2) == 0
+    k2 = c.download_kept()
+    d2 = tj.decode_meta(k2["meta"])
+    assert (k2["ctx0"] == kept["ctx0"]).all() and (k2["ctx1"] == kept["ctx1"]).all() and (d2["count"] == 2 * d["count"]).all()
+    assert c.coverage == 2 * cov
+    c.close()
+
+
+# ---- "next" rows: context grouping (N3), tract ids and the in-process exchange (N1), batched window rescans (N4) ------
+
+@pytest.mark.parametrize("k,maxd", [(10, 1), (10, 2), (10, 3), (25, 2)])
+def test_group_contexts_matches_the_oracle(k, maxd):
+    """tjamd_group_contexts == the oracle's restatement of the reference's greedy grouping (src/context_histogram.c:245-270,
+    distance :25-48) on a finalised sample that holds families of contexts 0-3 substitutions apart"""
+    rng = random.Random(100 * k + maxd)
+    mask = (1 << (2 * k)) - 1
+    e = []
+    for fam in range(3000):
+        c0, c1, base = rng.getrandbits(2 * k) & mask, rng.getrandbits(2 * k) & mask, rng.randrange(2)
+        for member in range(rng.choice([1, 1, 2, 3, 5])):
+            a, b = c0, c1
+            for _ in range(rng.choice([0, 1, 1, 2, 3])):
+                if rng.random() < 0.5:
+                    a ^= rng.randrange(1, 4) << (2 * rng.randrange(k))
+                else:
+                    b ^= rng.randrange(1, 4) << (2 * rng.randrange(k))
+            for length in rng.sample(range(3, 12), rng.choice([1, 2, 3])):
+                e += [(a, b, base, length)] * rng.randrange(2, 6)
+    raw = np.zeros(len(e), dtype=tj.ELEM_DTYPE)
+    for i, (a, b, base, length) in enumerate(e):
+        raw["ctx0"][i], raw["ctx1"][i] = a, b
+        raw["meta"][i] = base | (length << 2) | (1 << 12) | (0xffe << 32) | (1 << 49)
+    raw["read_offset"] = 0; raw["loc_ref_id"] = raw["loc_pos"] = raw["loc_last"] = -1
+    c = tj.Counter(k)
+    c.upload_raw(raw)
+    assert c.finalise(0, 0) == 0
+    kept = c.download_kept()
+    gof, grp = c.group_contexts(maxd)
+    ogof, first, nel, nctx, integ, mode = orc.group_contexts(kept, maxd)
+    assert len(grp) == len(first) and (gof == ogof).all()
+    assert (grp["first"] == first).all() and (grp["n_elem"] == nel).all() and (grp["n_context"] == nctx).all()
+    assert (grp["integral"] == integ).all() and (grp["mode"] == mode).all()
+    if maxd > 1:
+        assert len(grp) < len(np.unique(np.stack([kept["ctx0"], kept["ctx1"]], 1), axis=0))     # something was grouped
+    c.close()
+
+
+def test_tract_ids_and_in_process_gather():
+    """tjamd_gather_histograms (the exchange for samples that are threads of one process, as in the reference) followed by
+    tjamd_merge_samples == the python-side exchange; tjamd_tract_ids == the oracle's id pass over the union"""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from tatajuba_amd.dist import merge_histograms_host, device_bytes_tensor
+    k, counters = 10, []
+    for smp in range(3):
+        s = tj.synth_stream(30000, 150, 200000, seed_reads=0x7A7A1000 + smp, variant_seed=smp)
+        c = tj.Counter(k)
+        c.scan_host(s, 3)
+        assert c.finalise(1, 0) == 0
+        counters.append(c)
+    L = tj.lib()
+    hs = (C.c_void_p * 3)(*[c._h for c in counters])
+    drec, counts = C.c_void_p(), (C.c_long * 3)()
+    total = L.tjamd_gather_histograms(counters[0]._h, hs, 3, C.byref(drec), counts)
+    assert total == sum(c.n_kept for c in counters) and list(counts) == [c.n_kept for c in counters]
+    rec = device_bytes_tensor(drec.value, total * 24, torch.device("cuda", 0)).cpu().numpy()
+    parts = [device_bytes_tensor(c.kept_device_ptr, c.n_kept * 24, torch.device("cuda", 0)).cpu().numpy() for c in counters]
+    assert rec.tobytes() == b"".join(p.tobytes() for p in parts)
+    keys = torch.empty(total * 24, dtype=torch.uint8, device="cuda")
+    mat = torch.empty((total, 3), dtype=torch.int32, device="cuda")
+    nu = L.tjamd_merge_samples(counters[0]._h, drec, counts, 3, C.c_void_p(keys.data_ptr()), C.c_void_p(mat.data_ptr()), total)
+    keys_h, mat_h = merge_histograms_host(rec, list(counts))
+    assert nu == len(keys_h) and (mat[:nu].cpu().numpy() == mat_h).all()
+    ids = np.zeros(nu, np.int32)
+    nid = L.tjamd_tract_ids(counters[0]._h, C.c_void_p(keys.data_ptr()), nu, None, ids.ctypes.data)
+    kd = np.frombuffer(keys[: nu * 24].cpu().numpy().tobytes(), dtype=np.uint64).reshape(-1, 3)
+    oids, onid = orc.tract_ids(kd)
+    assert nid == onid and (ids == oids).all() and 0 < nid < nu
+    for c in counters:
+        c.close()
+
+
+def test_merge_samples_c_example(tmp_path):
+    """examples/merge_samples.c: two samples, two counters, gather + merge + tract ids from plain C, no Python in the loop"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, libdir = str(tmp_path / "merge_samples"), os.path.join(root, "tatajuba_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "merge_samples.c"),
+                           "-L", libdir, "-ltatajuba_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    files, kept = [], []
+    for smp in range(2):
+        s = tj.synth_stream(20000, 150, 100000, seed_reads=0x7A7A1000 + smp, variant_seed=smp)
+        reads = bytes(s).split(b"\n")[:-1]
+        f = str(tmp_path / f"s{smp}.fq")
+        with open(f, "wb") as fh:
+            fh.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads)))
+        files.append(f)
+        c = tj.Counter(10)
+        c.scan_host(s, 3)
+        assert c.finalise(1, 5) == 0
+        kept.append(c.download_kept())
+        c.close()
+    r = subprocess.run([exe, "-k", "10", "-m", "3", "-c", "5"] + files, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    keysets = [set(zip(tj.decode_meta(x["meta"])["base"].tolist(), x["ctx0"].tolist(), x["ctx1"].tolist(), tj.decode_meta(x["meta"])["length"].tolist())) for x in kept]
+    union, both = keysets[0] | keysets[1], keysets[0] & keysets[1]
+    contexts = {(b, a0, a1) for (b, a0, a1, _) in union}
+    assert f"merged: {len(kept[0]) + len(kept[1])} bars gathered, {len(union)} in the union, {len(both)} seen in every sample, {len(contexts)} tract ids" in r.stdout
+
+
+def test_scan_windows_batch_matches_single_calls_and_is_fast():
+    """tjamd_scan_windows: the reference's per-window rescans (src/genome_set.c:525-577: one counter and one
+    update_hopo_counter_from_seq per ~100-base window) as one launch; same records as the oracle window by window, m = 2 and
+    the all-monomers mode; 10 000 windows well under 50 ms"""
+    import ctypes as C
+    import time
+    rng = random.Random(3)
+    k, nw = 8, 10000
+    wins = ["".join(rng.choice("ACGT") for _ in range(rng.randrange(60, 140))) for _ in range(nw)]
+    wins[5] = "ACGT"                                         # shorter than k: nothing
+    wins[6] = ""
+    arr = (C.c_char_p * nw)(*[w.encode() for w in wins])
+    lens = (C.c_int * nw)(*[len(w) for w in wins])
+    L = tj.lib()
+    for m in (2, 0):
+        cap = sum(len(w) for w in wins) + 16
+        out = np.zeros(cap, dtype=tj.ELEM_DTYPE)
+        wof = np.zeros(cap, dtype=np.int32)
+        n = L.tjamd_scan_windows(k, arr, lens, nw, m, out.ctypes.data, wof.ctypes.data, cap)     # warm-up + result
+        t = time.perf_counter()
+        n2 = L.tjamd_scan_windows(k, arr, lens, nw, m, out.ctypes.data, wof.ctypes.data, cap)
+        dt = time.perf_counter() - t
+        assert n == n2 > 0 and dt < 0.05, dt
+        exp, expw = [], []
+        for i in list(range(0, 40)) + list(range(nw - 40, nw)):
+            o = orc.Oracle(k)
+            (o.scan_seq(wins[i], m) if m else o.scan_seq_all_monomers(wins[i]))
+            exp.append(o.elems().copy()); expw += [i] * len(exp[-1])
+            o.close()
+        sel = np.isin(wof[:n], np.array(sorted(set(expw)) + [5, 6]))
+        got = out[:n][sel]
+        assert got.tobytes() == np.concatenate(exp).tobytes() and wof[:n][sel].tolist() == expw
+        assert (np.diff(wof[:n]) >= 0).all()
