@@ -375,8 +375,13 @@ __device__ __forceinline__ void lds_dma16 (const void *gptr, void *lds_wave_base
 {
   const u32 m0v = (u32) __builtin_amdgcn_readfirstlane ((int) (u32) (size_t) (lptr_t) lds_wave_base);
   u32 saved;                                            // (M0 is the compiler's: put it back)
+#ifdef TJ_EXP_NT
+  asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                : "=&s"(saved) : "v"(gptr), "s"(m0v) : "memory");
+#else
   asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                 : "=&s"(saved) : "v"(gptr), "s"(m0v) : "memory");
+#endif
 }
 __device__ __forceinline__ void issue_chunk (const uint8_t *__restrict__ seq, long n_bytes, long g, uint4 *lds_wave_base)
 {
@@ -969,6 +974,9 @@ struct StageSink
   __device__ __forceinline__ void partition ()
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef TJ_EXP_PRIO
+    __builtin_amdgcn_s_setprio (TJ_EXP_PRIO);
+#endif
     lds_barrier ();                                     // every append so far is in LDS
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 1            // experiment builds only: records dropped
     if (tid == 0) L.n = 0;
@@ -1063,6 +1071,9 @@ struct StageSink
       }
     }
     lds_barrier ();                                     // the staging buffer is free again
+#ifdef TJ_EXP_PRIO
+    __builtin_amdgcn_s_setprio (0);
+#endif
     PSTAMP (15);
   }
 
@@ -1251,18 +1262,29 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   long grp_end = tile + FK_GROUP;
   u32 gpar = 0, it = 0;
 
-  // a tile is done here iff its whole window, and the four bytes in front of it, lie inside the stream
-  auto interior = [&] (long t) { const long g = t * (long) FK_OWN - FK_HL; return !all_slow && g >= 16 && g + (long) FK_WIN <= n_bytes; };
+  // A tile whose window (and the four bytes in front of it) lies inside the stream takes the straight path; the
+  // stream's first and last tiles are done here too: their chunks that stick out are fetched from a valid address
+  // instead and phase 1 overwrites what lies outside the stream with read delimiters (edge_words).
+  auto interior = [&] (long t) { const long g = t * (long) FK_OWN - FK_HL; return g >= 16 && g + (long) FK_WIN <= n_bytes; };
+  auto taken = [&] (long t) { return !all_slow; };
   // next tile's bytes: HBM -> LDS, 2 KiB per wave (two instructions of 1 KiB), and the word in front of the wave's
-  // first byte through the scalar cache
+  // first byte
   u32 pred = 0;
   auto prefetch = [&] (long t) {
-    const uint8_t *g = seq + (t * (long) FK_OWN - FK_HL) + 2048l * wave;
-    lds_dma16 (g + 16l * lane, &raw[128 * wave]);
-    lds_dma16 (g + 1024l + 16l * lane, &raw[128 * wave + 64]);
-    pred = *reinterpret_cast<const u32 *> (g - 4);
+    const long g0w = (t * (long) FK_OWN - FK_HL) + 2048l * wave;          // stream position of the wave's first byte
+    if (interior (t)) {
+      const uint8_t *g = seq + g0w;
+      lds_dma16 (g + 16l * lane, &raw[128 * wave]);
+      lds_dma16 (g + 1024l + 16l * lane, &raw[128 * wave + 64]);
+      pred = *reinterpret_cast<const u32 *> (g - 4);
+    }
+    else {
+      issue_chunk (seq, n_bytes, g0w + 16l * lane, &raw[128 * wave]);
+      issue_chunk (seq, n_bytes, g0w + 1024l + 16l * lane, &raw[128 * wave + 64]);
+      pred = stream_byte (seq, n_bytes, g0w - 1) << 24;
+    }
   };
-  if (tile < n_ftiles && interior (tile)) prefetch (tile);
+  if (tile < n_ftiles && taken (tile)) prefetch (tile);
 
   STAMP_DECL;
   while (tile < n_ftiles) {
@@ -1270,7 +1292,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     if (tid == 0 && tile + FK_GROUP == grp_end) T.grp[gpar ^ 1u] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP);
     const u32 slot = it % 3u, slot2 = (it + 2u) % 3u;
     if (tid == 0) { T.ncand[slot2] = 0; T.bad[slot2] = 0; }
-    const bool inside = interior (tile);
+    const bool inside = taken (tile);
     u32 S32 = 0, L32 = 0;
     const u32 pred_now = pred;
     if (inside) {
@@ -1278,7 +1300,18 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has landed in raw
       STAMP (1);
       const uint4 va = raw[2 * tid], vb = raw[2 * tid + 1];
-      const u32 x[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+      u32 x[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+      if (!interior (tile)) {                           // (uniform; the stream's first and last tiles) chunks that are not wholly inside the stream: byte by byte
+        const long p0 = tile * (long) FK_OWN - FK_HL + 32l * tid;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const long g = p0 + 16l * h;
+          if (!(g >= 0 && g + 16 <= n_bytes)) {
+            const EdgeChunk e = edge_chunk (seq, n_bytes, g);      // (outside the stream everything is a read delimiter)
+            x[4 * h] = e.x; x[4 * h + 1] = e.y; x[4 * h + 2] = e.z; x[4 * h + 3] = e.w;
+          }
+        }
+      }
       // the word in front: the last word of the lane before (one DPP move); the wave's first lane has it from `pred`
       const u32 prevw = (u32) __builtin_amdgcn_update_dpp ((int) pred_now, (int) x[7], 0x138, 0xF, 0xF, false);   // wave_shr:1
       u32 selp = prevw & M07, bad = 0, r[8], sc[4] = {0, 0, 0, 0}, lc[4] = {0, 0, 0, 0};
@@ -1315,7 +1348,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     // the tile after this one
     const long nt = (tile + 1 < grp_end) ? tile + 1 : (long) T.grp[gpar ^ 1u];
     if (inside) asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw has been read: it may be refilled
-    if (nt < n_ftiles && interior (nt)) prefetch (nt);
+    if (nt < n_ftiles && taken (nt)) prefetch (nt);
     STAMP (3);
 
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 1          // experiment builds only (tools/exp_fast_phases.sh)

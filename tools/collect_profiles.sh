@@ -9,6 +9,10 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-io-stages "$@" > $O/bench_under_rocprof.json 2> $O/kt.err
 echo "kernel trace done" > $O/progress.txt
+if [ -n "$KT_ONLY" ]; then      # kernel trace + plain bench only (the configurations other than the headline)
+  python3 $R/bench.py --no-io-stages "$@" > $O/bench_plain.json 2> $O/bench_plain.err
+  exit 0
+fi
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-io-stages "$@" > $O/fetch.out 2> $O/fetch.err
 echo "fetch done" >> $O/progress.txt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-io-stages "$@" > $O/write.out 2> $O/write.err
