@@ -988,17 +988,37 @@ struct StageSink
     if (tid < TJ_P) L.hist[tid] = 0;
     lds_barrier ();
     if (tid == 0) L.n = 0;                              // (everybody has read it; the next appends come after the last barrier below)
+    // (every stage below first issues all its LDS loads, whatever the record count -- slot tid + r * BLOCK always exists --
+    // and only then uses them: with the loads inside the `i < n` branches each of a thread's R records paid its own
+    // LDS round trips, one after the other)
     u64 w[R][WS];
     u32 rk[R], bb[R];
+    if constexpr (BIG) {
 #pragma unroll
-    for (int r = 0; r < R; r++) {                       // my records, and their rank inside their bucket
-      const u32 i = (u32) tid + (u32) r * BLOCK;
-      bb[r] = TJ_EMPTY;
-      if (i < n) {
+      for (int r = 0; r < R; r++) {                     // my records ...
+        const u32 i = (u32) tid + (u32) r * BLOCK;
         bb[r] = L.bin[i];
 #pragma unroll
         for (int j = 0; j < WS; j++) w[r][j] = L.rec[i * WS + j];
-        rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {                     // ... and their rank inside their bucket
+        const u32 i = (u32) tid + (u32) r * BLOCK;
+        if (i < n) rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
+        else bb[r] = TJ_EMPTY;
+      }
+    }
+    else {                                              // (scan_bins_kernel, 80 registers: one record at a time)
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const u32 i = (u32) tid + (u32) r * BLOCK;
+        bb[r] = TJ_EMPTY;
+        if (i < n) {
+          bb[r] = L.bin[i];
+#pragma unroll
+          for (int j = 0; j < WS; j++) w[r][j] = L.rec[i * WS + j];
+          rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
+        }
       }
     }
     lds_barrier ();
@@ -1025,14 +1045,28 @@ struct StageSink
     }
     lds_barrier ();
     PSTAMP (11);
+    if constexpr (BIG) {
+      u32 dst[R];
 #pragma unroll
-    for (int r = 0; r < R; r++)                          // in-place permutation into bucket order (records are in registers)
-      if (bb[r] != TJ_EMPTY) {
-        const u32 d = L.offs[bb[r]] + rk[r];
+      for (int r = 0; r < R; r++) dst[r] = L.offs[bb[r] & (TJ_P - 1)] + rk[r];
 #pragma unroll
-        for (int j = 0; j < WS; j++) L.rec[d * WS + j] = w[r][j];
-        L.bin[d] = (unsigned char) bb[r];
-      }
+      for (int r = 0; r < R; r++)                        // in-place permutation into bucket order (records are in registers)
+        if (bb[r] != TJ_EMPTY) {
+#pragma unroll
+          for (int j = 0; j < WS; j++) L.rec[dst[r] * WS + j] = w[r][j];
+          L.bin[dst[r]] = (unsigned char) bb[r];
+        }
+    }
+    else {
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (bb[r] != TJ_EMPTY) {
+          const u32 d = L.offs[bb[r]] + rk[r];
+#pragma unroll
+          for (int j = 0; j < WS; j++) L.rec[d * WS + j] = w[r][j];
+          L.bin[d] = (unsigned char) bb[r];
+        }
+    }
     PSTAMP (12);
     if (tid < TJ_P && cnt) {                            // where the reserved run lives
       const u32 ch = (u32) TJ_CH0 << B.ch_shift;
@@ -1052,21 +1086,50 @@ struct StageSink
     PSTAMP (13);
     lds_barrier ();
     PSTAMP (14);
+    if constexpr (BIG) {
+      u32 cb[R], co[R], csp[R];
+      u64 cg1[R], cg2[R], cw[R][WS];
 #pragma unroll
-    for (int r = 0; r < R; r++) {                       // sorted slot i -> its place in the bucket's run (coalesced per run)
-      const u32 i = (u32) tid + (u32) r * BLOCK;
-      if (i < n) {
-        const u32 b = L.bin[i], o = i - L.offs[b], sp = L.split[b];
-        const u64 g = (o < sp) ? L.gbase[b] : L.gbase2[b];
+      for (int r = 0; r < R; r++) cb[r] = L.bin[(u32) tid + (u32) r * BLOCK];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const u32 i = (u32) tid + (u32) r * BLOCK;
+        co[r] = i - L.offs[cb[r]]; csp[r] = L.split[cb[r]]; cg1[r] = L.gbase[cb[r]]; cg2[r] = L.gbase2[cb[r]];
+#pragma unroll
+        for (int j = 0; j < WS; j++) cw[r][j] = L.rec[i * WS + j];
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {                     // sorted slot i -> its place in the bucket's run (coalesced per run)
+        const u32 i = (u32) tid + (u32) r * BLOCK;
+        if (i < n) {
+          const u32 o = co[r], sp = csp[r];
+          const u64 g = (o < sp) ? cg1[r] : cg2[r];
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 3
-        if (g == 0x123456789ull) {
+          if (g == 0x123456789ull) {
 #else
-        if (g != ~0ull) {
+          if (g != ~0ull) {
 #endif
-          u64 *q = B.pool + (g + (o < sp ? o : o - sp)) * W;
+            u64 *q = B.pool + (g + (o < sp ? o : o - sp)) * W;
 #pragma unroll
-          for (int j = 0; j < WS; j++) q[j] = L.rec[i * WS + j];
-          if (WS < W) q[W - 1] = 0;
+            for (int j = 0; j < WS; j++) q[j] = cw[r][j];
+            if (WS < W) q[W - 1] = 0;
+          }
+        }
+      }
+    }
+    else {
+#pragma unroll
+      for (int r = 0; r < R; r++) {                     // sorted slot i -> its place in the bucket's run (coalesced per run)
+        const u32 i = (u32) tid + (u32) r * BLOCK;
+        if (i < n) {
+          const u32 b = L.bin[i], o = i - L.offs[b], sp = L.split[b];
+          const u64 g = (o < sp) ? L.gbase[b] : L.gbase2[b];
+          if (g != ~0ull) {
+            u64 *q = B.pool + (g + (o < sp ? o : o - sp)) * W;
+#pragma unroll
+            for (int j = 0; j < WS; j++) q[j] = L.rec[i * WS + j];
+            if (WS < W) q[W - 1] = 0;
+          }
         }
       }
     }
@@ -1213,15 +1276,14 @@ __device__ __forceinline__ bool fast_tract (const FastLds &T, const uint8_t *__r
   return true;
 }
 
-// the same, out of line, for the tracts that do not fit the one-word kernel's straight-line path (k + length + k > 32)
-__device__ __noinline__ bool fast_general_tract (const FastLds &T, const uint8_t *__restrict__ seq, long n_bytes, long g0, int s, int k, int mprime,
-                                                 u32 &lo, u32 &hi)
+// the same, out of line, for the tracts that do not fit the one-word kernel's straight-line path (k + length + k > 32).
+// Returns the packed record, 0 if the tract is not recorded (a record is never 0; by value: a reference parameter of a
+// function that is not inlined would put the caller's variables into scratch memory, in every round).
+__device__ __noinline__ u64 fast_general_tract (const FastLds &T, const uint8_t *__restrict__ seq, long n_bytes, long g0, int s, int k, int mprime)
 {
   u64 c0, c1; u32 base, len10, flag;
-  if (!fast_tract<true> (T, seq, n_bytes, g0, s, k, mprime, c0, c1, base, len10, flag)) return false;
-  const u64 rec = pack_rec1 ((u32) c0, (u32) c1, base, len10, flag);
-  lo = (u32) rec; hi = (u32) (rec >> 32);
-  return true;
+  if (!fast_tract<true> (T, seq, n_bytes, g0, s, k, mprime, c0, c1, base, len10, flag)) return 0ull;
+  return pack_rec1 ((u32) c0, (u32) c1, base, len10, flag);
 }
 
 template <int W>
@@ -1437,7 +1499,10 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
           lo = c1 | (len << 24);
           hi = c0 | (fld << 24);
         }
-        if (general) ok = fast_general_tract (T, seq, n_bytes, g0, (int) s, k, mprime, lo, hi);
+        if (general) {
+          const u64 rec = fast_general_tract (T, seq, n_bytes, g0, (int) s, k, mprime);
+          ok = rec != 0ull; lo = (u32) rec; hi = (u32) (rec >> 32);
+        }
         STAMP (6);
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
         if (ok) asm volatile ("" :: "v"(lo), "v"(hi));
