@@ -1157,6 +1157,7 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
   __shared__ TileLds<TJ_SB_BLOCK, TJ_SB_TILE> T;
   __shared__ uint4 raw[TileLds<TJ_SB_BLOCK, TJ_SB_TILE>::NRAW];
   __shared__ StageLds<W> SL;
+  if (src.list && ctr->lc[par].n_slow == 0) return;     // (the usual case behind the fast kernel: nothing was left over)
   StageSink<W, TJ_SB_BLOCK> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
   sink.start ();
   scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE, 2> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap, par, src);
