@@ -5,15 +5,15 @@
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; libtatajuba_amd.so never links or
  * calls anything in this directory.
  *
- * PINNING.  The reference's own tests hold no vector for this path (tests/check_bwa.c only exercises BWA).  The
- * real reference cannot be built here as oracle/_ref: src/hopo_counter.c includes <biomcmc.h> and <wrapper_bwa.h>
+ * PINNING: PARTIAL.  The reference's own tests hold no vector for this path (tests/check_bwa.c only exercises BWA).
+ * The real reference cannot be built here as oracle/_ref: src/hopo_counter.c includes <biomcmc.h> and <wrapper_bwa.h>
  * from two submodules that are empty in /root/reference, and writing stand-in headers for them is ruled out, so it
- * is "unbuildable" and oracle/_ref does not exist.  This restatement is therefore pinned by
- *   (1) the documentation-level known answer in the reference's README.md:226-230, and
- *   (2) the known-answer vectors of SURVEY.md section 9.7 -- outputs of the unmodified reference hopo_counter.c
- *       recorded by the survey stage in this container, including whole-file aggregates and the first kept rows for
- *       the reference's own data file tests/files/err1750956.fastq.gz at four parameter sets --
- * all committed under tests/golden/ and checked by tests/test_oracle_golden.py.
+ * is "unbuildable" and oracle/_ref does not exist.  What the reference does hold is checked in
+ * tests/test_oracle_golden.py::test_reference_figure_and_readme_names: the three tracts of its figure
+ * recipe/200322_001.png (read -> stored context, base, length; the T tract is the only reference-held statement of the
+ * reverse-complement canonicalisation) and the names README.md:226-230 prints for them.  The other vectors under
+ * tests/golden/  were recorded by a survey-stage probe that compiled hopo_counter.c against stub
+ * headers; they document what this file was written to and do not pin it.
  *
  * Deliberate differences from the reference (all on undefined behaviour):
  *   - a qualifying run of a non-ACGTU byte with NO earlier tract in the same read makes the reference append a record
