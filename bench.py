@@ -140,6 +140,49 @@ def io_stages(tj, host, args, k, m, L):
         h.delete()
     res["from_file"] = {"reads_per_s": len(reads) / best, "file_MB": os.path.getsize(fq) / 1e6, "seconds": best, "reads": len(reads),
                         "note": "plain FASTQ -> new_or_append_hopo_counter_from_file (multi-threaded feeder) + finalise_hopo_counter"}
+    # the same records gzip-compressed, the way read files usually arrive: one gzip member (inflate on one thread, running
+    # ahead of the parse) and BGZF (bgzip: 64 KiB members inflated side by side); qualities drawn from 8 levels so that the
+    # compression ratio is that of real files rather than of a constant string
+    import struct
+    import zlib
+    n_gz = min(len(reads), args.gz_reads)
+    rng = np.random.default_rng(5)
+    levels = np.frombuffer(b"#-27<AFI", np.uint8)
+    chunks = []
+    for i in range(0, n_gz, 100000):
+        js = range(i, min(n_gz, i + 100000))
+        q = levels[rng.integers(0, 8, size=sum(len(reads[j]) for j in js))].tobytes()
+        off, recs = 0, []
+        for j in js:
+            recs.append(b"@r%d\n%s\n+\n%s\n" % (j, reads[j], q[off:off + len(reads[j])]))
+            off += len(reads[j])
+        chunks.append(b"".join(recs))
+    txt = b"".join(chunks)
+
+    def member(data, bgzf):
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = co.compress(data) + co.flush()
+        tail = struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+        if not bgzf:
+            return b"\x1f\x8b\x08\x00" + b"\0" * 4 + b"\x00\xff" + body + tail
+        return b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1) + body + tail
+
+    for key, blob, how in (("from_gzip", member(txt, False), "one gzip member: inflate on one thread, one window ahead of the parse"),
+                           ("from_bgzf", b"".join(member(txt[i:i + 0xff00], True) for i in range(0, len(txt), 0xff00)) + member(b"", True),
+                            "BGZF: members inflated side by side by the feeder threads")):
+        gz = os.path.join(tmp, key + ".fq.gz")
+        with open(gz, "wb") as f:
+            f.write(blob)
+        best = 1e9
+        for rep in range(2):
+            t = time.perf_counter()
+            h = tj.HopoCounter.new_or_append_from_file(None, gz, opt)
+            h.finalise()
+            best = min(best, time.perf_counter() - t)
+            h.delete()
+        res[key] = {"reads_per_s": n_gz / best, "file_MB": len(blob) / 1e6, "inflated_MB": len(txt) / 1e6, "seconds": best, "reads": n_gz,
+                    "note": how + " -> new_or_append_hopo_counter_from_file + finalise_hopo_counter"}
+        os.remove(gz)
     os.remove(fq)
     os.rmdir(tmp)
     return res
@@ -163,6 +206,7 @@ def main():
                     help="a BASELINE.json configuration (SURVEY 8d numbering; 2 = configs[1] = the headline = the default sizes)")
     ap.add_argument("--no-io-stages", action="store_true", help="skip the host-memory and FASTQ-file throughputs (stages.from_host / from_file)")
     ap.add_argument("--io-reads", type=int, default=2_000_000, help="reads of the sample used for stages.from_host / from_file")
+    ap.add_argument("--gz-reads", type=int, default=500_000, help="reads of the sample used for stages.from_gzip / from_bgzf")
     ap.add_argument("--rehearse", action="store_true", help="launch plumbing only, no GPU work (CPU tests)")
     args = ap.parse_args()
     if args.config is not None:

@@ -71,11 +71,12 @@ long tjamd_scan_windows (int kmer_size, const char *const *seqs, const int *lens
  * when capacity suffices (call with out = NULL to size); *n_reads = records parsed; -1 if the file cannot be opened. */
 long tjamd_read_file_stream (const char *path, unsigned char *out, long capacity, long *n_reads);
 
-/* The same through the multi-threaded feeder (uncompressed files; a gzip file goes to the function above): n_threads
- * readers over one mapped file, window_bytes of it at a time (0 = default), their outputs accepted only where each
- * reader ended exactly on the next one's first record -- so the result is byte-identical to tjamd_read_file_stream.
- * new_or_append_hopo_counter_from_file takes this path for plain files of 32 MiB and more
- * (TATAJUBA_AMD_FEEDER_THREADS, default min(8, cores)). */
+/* The same through the multi-threaded feeder (tatajuba_amd/csrc/feeder.c): n_threads readers over window_bytes of
+ * file bytes at a time (0 = default), their outputs accepted only where each reader ended exactly on the next one's
+ * first record -- so the result is byte-identical to tjamd_read_file_stream.  A plain file is mapped; a gzip file is
+ * inflated one window ahead of the parse, BGZF (bgzip) members by all threads side by side, any other gzip stream by
+ * one thread.  new_or_append_hopo_counter_from_file takes this path for plain files of 32 MiB and gzip files of 4 MiB
+ * and more (TATAJUBA_AMD_FEEDER_THREADS, default min(8, cores); 1 = the single reader). */
 long tjamd_read_file_stream_mt (const char *path, unsigned char *out, long capacity, long *n_reads, int n_threads, long window_bytes);
 
 /* pinned host memory, so that tjamd_scan_host overlaps the copy with the caller's parsing; tjamd_sync waits for

@@ -19,6 +19,7 @@ struct tjr_reader
   int in_memory;        /* blk is the caller's (whole input, nothing to refill or free) */
   size_t marker_pos;    /* offset in blk of the marker of the next record (marker_seen) / of the record returned last */
   size_t rec_start;
+  int rec_open;         /* the last tjr_next() found a record marker (rec_start is that record's) */
   tjr_text seq, qual;
 };
 
@@ -101,6 +102,8 @@ tjr_open_mem (const unsigned char *data, size_t n_bytes, size_t start)
 }
 
 size_t tjr_record_start (const tjr_reader *r) { return r->rec_start; }
+int tjr_record_open (const tjr_reader *r) { return r->rec_open; }
+int tjr_at_end (const tjr_reader *r) { return r->drained && r->pos >= r->end; }
 
 void
 tjr_close (tjr_reader *r)
@@ -115,12 +118,14 @@ tjr_next (tjr_reader *r, const char **seq)
 {
   int c;
   unsigned char ch;
+  r->rec_open = 0;
   if (!r->marker_seen) {                       /* hunt for the next record marker, wherever it is */
     do c = tjr_byte (r); while (c != -1 && c != '>' && c != '@');
     if (c == -1) return -1;
     r->marker_pos = r->pos - 1;
   }
   r->rec_start = r->marker_pos;
+  r->rec_open = 1;
   r->marker_seen = 0;
   r->seq.len = r->qual.len = 0;
   if (tjr_line (r, NULL) < 0) return -1;       /* header line: name and comment are not needed */

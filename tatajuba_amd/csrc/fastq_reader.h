@@ -19,5 +19,10 @@ void tjr_close (tjr_reader *r);
  * multi-threaded feeder's consistency check rests on. */
 tjr_reader *tjr_open_mem (const unsigned char *data, size_t n_bytes, size_t start);
 size_t tjr_record_start (const tjr_reader *r);
+/* For input that arrives in pieces (feeder.c, gzip): after a tjr_next(), tjr_at_end() says that the reader touched the
+ * end of its bytes -- the record it returned (or failed to return) may be cut short and has to be read again from
+ * tjr_record_start() once more bytes are there; tjr_record_open() = 0 if that call found no record marker at all. */
+int tjr_at_end (const tjr_reader *r);
+int tjr_record_open (const tjr_reader *r);
 
 #endif

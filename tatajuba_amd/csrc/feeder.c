@@ -1,20 +1,27 @@
-/* feeder.c -- multi-threaded host feeder for plain (uncompressed) FASTA/FASTQ files.
+/* feeder.c -- multi-threaded host feeder for FASTA/FASTQ files, plain or gzip.
  *
  * The reference parses with kseq, a byte-at-a-time state machine (src/kseq.h:172-212, used at
  * src/hopo_counter.c:142-155); the single-threaded restatement of it is fastq_reader.c and stays the definition of
- * what a file contains.  This file runs SEVERAL of those readers over one memory-mapped file and proves, window by
- * window, that their concatenated output is what one reader would have produced:
+ * what a file contains.  This file runs SEVERAL of those readers over one stretch of file bytes in memory and proves,
+ * window by window, that their concatenated output is what one reader would have produced:
  *
- *   - the file is cut into windows, a window into one range per thread; range starts inside the window are GUESSES
+ *   - the bytes are cut into windows, a window into one range per thread; range starts inside the window are GUESSES
  *     (a line that starts with '@' or '>' and, for '@', is followed by a sequence line, a '+' line and a quality line
  *     of the same length);
  *   - every thread runs the ordinary reader from its start (fresh state) and stops at the first record that begins
  *     at or after the next range's start; tjr_record_start() tells where each record began;
  *   - the window is accepted iff every thread stopped EXACTLY at the next thread's start.  A fresh reader placed on
  *     the first byte of a record is in the same state as the reader that arrived there (see fastq_reader.h), so by
- *     induction over the ranges the concatenation equals the sequential parse.  Anything else (a wrong guess, a
- *     record longer than a range, ...) discards the results from the first inconsistent range on and the rest of
- *     the file is parsed by one reader.
+ *     induction over the ranges the concatenation equals the sequential parse.  Where a range did not land (a wrong
+ *     guess, a record longer than a range, ...) the results of the ranges after it are discarded and one reader
+ *     takes the rest of that window; the next window is cut afresh.
+ *
+ * A plain file is mapped whole and the windows walk over it.  A gzip file (the usual input: the reference opens
+ * everything through zlib, src/hopo_counter.c:142) is inflated a VIEW at a time by a producer thread that runs one
+ * view ahead of the parse: BGZF files (bgzip: independent members that state their compressed and uncompressed
+ * sizes) by all threads at once, any other gzip stream by one thread (deflate cannot be entered in the middle).  A
+ * view ends wherever the inflated bytes happened to end; the last reader of a view gives back the record it was in
+ * when it touched the end (tjr_at_end), and those bytes open the next view.
  *
  * Output goes to a sink in file order (the device scan does not care about order, the tests do).
  */
@@ -29,25 +36,33 @@
 #include <unistd.h>
 #include <stdio.h>
 #include <time.h>
+#include <zlib.h>
 
 static double tjf_now (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec; }
 
-static long tjf_stat_windows = 0, tjf_stat_fallback = 0;   /* of the last tjf_parse_file call (diagnostics, tests) */
+static long tjf_stat_windows = 0, tjf_stat_fallback = 0, tjf_stat_bgzf = 0;   /* of the last parse call (diagnostics, tests) */
 void tjf_last_stats (long *windows, long *fell_back) { if (windows) *windows = tjf_stat_windows; if (fell_back) *fell_back = tjf_stat_fallback; }
+long tjf_last_bgzf_blocks (void) { return tjf_stat_bgzf; }
 
-enum { TJF_LANDED = 0, TJF_MISMATCH = 1, TJF_BADQUAL = 2, TJF_EOF = 3, TJF_OVERFLOW = 4 };
+enum { TJF_LANDED = 0, TJF_MISMATCH = 1, TJF_BADQUAL = 2, TJF_EOF = 3, TJF_OVERFLOW = 4, TJF_CUT = 5 };
 
 typedef struct
 {
   const unsigned char *data;
   size_t n, start, stop;
   int is_last;
+  int open_end;         /* the bytes are a view of an unfinished file: give back the record that is cut by their end */
   unsigned char *out;
   size_t out_cap, out_len, end_pos;
   long n_reads;
   int status;
 } tjf_job;
 
+/* One range.  Its start is a record start that is proven by the time the output is used, so what it emits is right
+ * whatever happens to the ranges after it; status says how it ended: LANDED on the next range's start, MISMATCH (the
+ * first record at or after `stop` starts somewhere else, at end_pos: the next start was a wrong guess), CUT (view only:
+ * end_pos is the record to read again when more bytes are there), EOF / BADQUAL (the file ends here for any reader),
+ * OVERFLOW (the output buffer is too small: nothing of this range is used). */
 static void *
 tjf_run (void *arg)
 {
@@ -58,7 +73,12 @@ tjf_run (void *arg)
   j->out_len = 0; j->n_reads = 0; j->end_pos = j->n; j->status = TJF_EOF;
   for (;;) {
     len = tjr_next (r, &seq);
-    if (len == -1) { j->status = (j->is_last || j->stop >= j->n) ? TJF_EOF : TJF_MISMATCH; break; }
+    if (j->open_end && tjr_at_end (r)) {
+      j->end_pos = tjr_record_open (r) ? tjr_record_start (r) : j->n;
+      j->status = TJF_CUT;
+      break;
+    }
+    if (len == -1) { j->status = TJF_EOF; break; }
     {
       const size_t q = tjr_record_start (r);
       if (q >= j->stop) {                               /* the next range's business -- if it starts exactly there */
@@ -91,7 +111,11 @@ tjf_guess_start (const unsigned char *d, size_t n, size_t from, size_t limit)
     q = (size_t) (nl - d) + 1;                          /* a line start */
     if (q >= limit) break;
     p = q;
-    if (d[q] == '>') return q;
+    if (d[q] == '>') {                                  /* a FASTA header -- or a quality line (Phred 29), which a header line follows */
+      nl = (const unsigned char *) memchr (d + q, '\n', n - q);
+      if (nl && (size_t) (nl - d) + 1 < n && nl[1] != '@' && nl[1] != '>' && nl[1] != '+') return q;
+      continue;
+    }
     if (d[q] != '@') continue;
     /* '@' also opens quality lines: ask for header / sequence / '+' / quality of the sequence's length */
     nl = (const unsigned char *) memchr (d + q, '\n', n - q); if (!nl) continue; e1 = (size_t) (nl - d); l1 = e1 + 1;
@@ -118,129 +142,453 @@ tjf_is_plain_file (const char *path)
   return !(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
 }
 
-long
-tjf_parse_file (const char *path, int n_threads, size_t window_bytes, const tjf_sink *sink)
+/* ---- the windowed parse over bytes in memory ---------------------------------------------------------------------- */
+
+typedef struct
 {
-  struct stat st;
-  const unsigned char *data;
-  size_t n, pos = 0, cap;
-  long total_reads = 0;
-  int fd, i, set = 0, done = 0, fell_back = 0;
+  const tjf_sink *sink;
+  int n_threads;
+  size_t cap;
   unsigned char *buf[2][TJF_MAX_THREADS];
+  long set_mark[2];
+  int set;
+  long n_windows;
+  long total_reads;     /* < 0: -2 out of memory, -3 the sink failed */
+  int done;             /* the file ends here for the reference too (bad quality string), or an error */
+  double t_alloc, t_parse, t_put, t_sync;
+} tjf_state;
+
+static int
+tjf_state_init (tjf_state *s, const tjf_sink *sink, int n_threads, size_t window_bytes)
+{
+  int set, i;
+  const double tt = tjf_now ();
+  memset (s, 0, sizeof *s);
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > TJF_MAX_THREADS) n_threads = TJF_MAX_THREADS;
+  s->sink = sink; s->n_threads = n_threads;
+  s->cap = 2 * (window_bytes / (size_t) n_threads) + (1u << 16);
+  s->set_mark[0] = s->set_mark[1] = -1;
+  for (set = 0; set < 2; set++) for (i = 0; i < n_threads; i++) {
+    s->buf[set][i] = (unsigned char *) sink->alloc (sink->ctx, s->cap);
+    if (!s->buf[set][i]) return -2;
+  }
+  s->t_alloc = tjf_now () - tt;
+  return 0;
+}
+
+static void
+tjf_state_free (tjf_state *s)
+{
+  int set, i;
+  for (set = 0; set < 2; set++) for (i = 0; i < s->n_threads; i++) if (s->buf[set][i]) s->sink->release (s->sink->ctx, s->buf[set][i]);
+}
+
+/* the buffer set about to be written was sent two windows ago: with marks only ITS batches are waited for (the window
+ * sent last is still in flight); every fourth window a full synchronisation lets the sink refresh what it knows (exact
+ * counts).  Returns != 0 if the sink failed. */
+static int
+tjf_claim_set (tjf_state *s)
+{
+  const tjf_sink *sink = s->sink;
+  const double tt = tjf_now ();
+  int bad = 0;
+  if (sink->mark && sink->wait) {
+    if (s->set_mark[s->set] >= 0 && sink->wait (sink->ctx, s->set_mark[s->set])) bad = 1;
+    else if ((s->n_windows & 3) == 3 && sink->sync && sink->sync (sink->ctx)) bad = 1;
+  }
+  else if (sink->sync && sink->sync (sink->ctx)) bad = 1;
+  s->n_windows++;
+  s->t_sync += tjf_now () - tt;
+  if (bad) { s->done = 1; s->total_reads = -3; }
+  return bad;
+}
+
+/* One reader over data[start, ...) up to the first record that begins at or after `stop`: the repair after a wrong
+ * guess or a range too big for its buffer.  Records go out through buffer 0 of the current set, which is flushed (and
+ * waited for) whenever it is full.  open_end as in tjf_job.  Returns the position reached. */
+static size_t
+tjf_sequential (tjf_state *s, const unsigned char *data, size_t n, size_t start, size_t stop, int open_end)
+{
+  const tjf_sink *sink = s->sink;
+  tjr_reader *r = tjr_open_mem (data, n, start);
+  unsigned char *b = s->buf[s->set][0];
+  const size_t cap = s->cap;
+  const char *seq;
+  size_t fill = 0, end_pos = n;
+  long len, nr = 0;
+  for (;;) {
+    len = tjr_next (r, &seq);
+    if (open_end && tjr_at_end (r)) { end_pos = tjr_record_open (r) ? tjr_record_start (r) : n; break; }
+    if (len == -1) { s->done = 1; break; }
+    if (tjr_record_start (r) >= stop) { end_pos = tjr_record_start (r); break; }
+    if (len == -2) { s->done = 1; break; }
+    if ((size_t) len + 1 > cap) {                       /* longer than a buffer: on its own */
+      unsigned char *big = (unsigned char *) malloc ((size_t) len + 1);
+      if (!big) { s->total_reads = -2; break; }
+      memcpy (big, seq, (size_t) len); big[len] = '\n';
+      if (fill && sink->put (sink->ctx, b, fill, nr)) { s->total_reads = -3; free (big); break; }
+      s->total_reads += nr; fill = 0; nr = 0;
+      if (sink->put (sink->ctx, big, (size_t) len + 1, 1) || (sink->sync && sink->sync (sink->ctx))) { s->total_reads = -3; free (big); break; }
+      s->total_reads += 1;
+      free (big);
+      continue;
+    }
+    if (fill + (size_t) len + 1 > cap) {
+      if (sink->put (sink->ctx, b, fill, nr) || (sink->sync && sink->sync (sink->ctx))) { s->total_reads = -3; break; }
+      s->total_reads += nr; fill = 0; nr = 0;
+    }
+    memcpy (b + fill, seq, (size_t) len); b[fill + (size_t) len] = '\n';
+    fill += (size_t) len + 1; nr++;
+  }
+  if (s->total_reads >= 0 && fill) {
+    if (sink->put (sink->ctx, b, fill, nr) || (sink->sync && sink->sync (sink->ctx))) s->total_reads = -3; else s->total_reads += nr;
+  }
+  tjr_close (r);
+  if (s->total_reads < 0) s->done = 1;
+  return end_pos;
+}
+
+/* One window: data[pos, wend) of data[0, n).  whole_file: the bytes are the whole rest of the file (the last range may
+ * read past wend); otherwise wend == n is where a view of an unfinished file ends.  Returns the position reached. */
+static size_t
+tjf_window (tjf_state *s, const unsigned char *data, size_t n, size_t pos, size_t wend, int whole_file)
+{
+  const tjf_sink *sink = s->sink;
+  size_t starts[TJF_MAX_THREADS + 1];
   tjf_job job[TJF_MAX_THREADS];
   pthread_t th[TJF_MAX_THREADS];
   int started[TJF_MAX_THREADS];
-  long set_mark[2] = {-1, -1};
-  long n_windows = 0;
+  int nj = 1, accepted, i, cut = 0, repair = 0;
+  size_t repair_from = 0;
+  double tt;
 
-  const int trace = getenv ("TATAJUBA_AMD_FEEDER_TRACE") != NULL;
-  double t0 = tjf_now (), t_alloc = 0, t_parse = 0, t_put = 0, t_sync = 0, tt;
-  if (n_threads < 1) n_threads = 1;
-  if (n_threads > TJF_MAX_THREADS) n_threads = TJF_MAX_THREADS;
-  fd = open (path, O_RDONLY);
-  if (fd < 0) return -1;
-  if (fstat (fd, &st) != 0 || st.st_size <= 0) { close (fd); return st.st_size == 0 ? 0 : -1; }
-  n = (size_t) st.st_size;
-  data = (const unsigned char *) mmap (NULL, n, PROT_READ, MAP_PRIVATE, fd, 0);
-  close (fd);
-  if (data == (const unsigned char *) MAP_FAILED) return -1;
-  (void) madvise ((void *) data, n, MADV_SEQUENTIAL);
-  if (window_bytes < 4096) window_bytes = 4096;
-  cap = 2 * (window_bytes / (size_t) n_threads) + (1u << 16);
-  tt = tjf_now ();
-  for (set = 0; set < 2; set++) for (i = 0; i < n_threads; i++) {
-    buf[set][i] = (unsigned char *) sink->alloc (sink->ctx, cap);
-    if (!buf[set][i]) { munmap ((void *) data, n); return -2; }
+  if (tjf_claim_set (s)) return pos;
+  starts[0] = pos;
+  for (i = 1; i < s->n_threads; i++) {                  /* guessed range starts, strictly increasing */
+    const size_t want = pos + (size_t) ((double) (wend - pos) * i / s->n_threads);
+    const size_t g = tjf_guess_start (data, n, want > starts[nj - 1] ? want : starts[nj - 1], wend);
+    if (g > starts[nj - 1] && g < wend) starts[nj++] = g;
   }
+  starts[nj] = wend;
+  tt = tjf_now ();
+  for (i = 0; i < nj; i++) {
+    job[i].data = data; job[i].n = n; job[i].start = starts[i]; job[i].stop = starts[i + 1]; job[i].is_last = (i == nj - 1);
+    job[i].open_end = !whole_file;
+    job[i].out = s->buf[s->set][i]; job[i].out_cap = s->cap;
+    started[i] = 0;
+    if (i) { if (pthread_create (&th[i], NULL, tjf_run, &job[i]) == 0) started[i] = 1; else tjf_run (&job[i]); }
+  }
+  tjf_run (&job[0]);
+  for (i = 1; i < nj; i++) if (started[i]) pthread_join (th[i], NULL);
+  s->t_parse += tjf_now () - tt; tt = tjf_now ();
 
-  t_alloc = tjf_now () - tt;
-  set = 0;
-  tjf_stat_windows = 0; tjf_stat_fallback = 0;
-  while (!done && pos < n) {
-    const size_t wend = (n - pos > window_bytes) ? pos + window_bytes : n;
-    size_t starts[TJF_MAX_THREADS + 1];
-    int nj = 1, accepted;
-    starts[0] = pos;
-    for (i = 1; i < n_threads; i++) {                   /* guessed range starts, strictly increasing */
-      const size_t want = pos + (size_t) ((double) (wend - pos) * i / n_threads);
-      const size_t g = tjf_guess_start (data, n, want > starts[nj - 1] ? want : starts[nj - 1], wend);
-      if (g > starts[nj - 1] && g < wend) starts[nj++] = g;
-    }
-    starts[nj] = wend;
+  accepted = 0;
+  for (i = 0; i < nj; i++) {                            /* the chain of ranges: each must end where the next begins */
+    const int st = job[i].status;
+    if (st == TJF_OVERFLOW) { repair = 1; repair_from = job[i].start; break; }
+    accepted++;                                         /* (it began on a proven record start: its records are right) */
+    if (st == TJF_BADQUAL || st == TJF_EOF) { s->done = 1; break; }
+    if (st == TJF_CUT) { cut = 1; break; }
+    if (st == TJF_MISMATCH) { repair = 1; repair_from = job[i].end_pos; break; }
+  }
+  if (!repair) tjf_stat_windows++;                      /* (the whole window came from the parallel readers) */
+  for (i = 0; i < accepted; i++) {
+    if (job[i].out_len && sink->put (sink->ctx, job[i].out, job[i].out_len, job[i].n_reads)) { s->done = 1; s->total_reads = -3; break; }
+    s->total_reads += job[i].n_reads;
+  }
+  if (s->total_reads >= 0 && sink->mark) { s->set_mark[s->set] = sink->mark (sink->ctx); if (s->set_mark[s->set] < 0) s->total_reads = -3; }
+  s->t_put += tjf_now () - tt;
+  if (s->total_reads < 0) { s->done = 1; return pos; }
+  s->set ^= 1;                                          /* (the set just sent is in flight) */
+  if (s->done) return n;
+  if (cut) return job[accepted - 1].end_pos;
+  if (repair) {                                         /* a wrong guess: one reader for the rest of this window */
+    tjf_stat_fallback++;
+    if (sink->sync && sink->sync (sink->ctx)) { s->done = 1; s->total_reads = -3; return pos; }
+    s->set_mark[0] = s->set_mark[1] = -1;
     tt = tjf_now ();
-    /* this buffer set was sent two windows ago: with marks only ITS batches are waited for (the window sent last is
-     * still in flight); every fourth window a full synchronisation lets the sink refresh what it knows (exact counts) */
-    if (sink->mark && sink->wait) {
-      if (set_mark[set] >= 0 && sink->wait (sink->ctx, set_mark[set])) { done = 1; total_reads = -3; break; }
-      if ((n_windows & 3) == 3 && sink->sync && sink->sync (sink->ctx)) { done = 1; total_reads = -3; break; }
-    }
-    else if (sink->sync && sink->sync (sink->ctx)) { done = 1; total_reads = -3; break; }
-    n_windows++;
-    t_sync += tjf_now () - tt; tt = tjf_now ();
-    for (i = 0; i < nj; i++) {
-      job[i].data = data; job[i].n = n; job[i].start = starts[i]; job[i].stop = starts[i + 1]; job[i].is_last = (i == nj - 1);
-      job[i].out = buf[set][i]; job[i].out_cap = cap;
-      started[i] = 0;
-      if (i) { if (pthread_create (&th[i], NULL, tjf_run, &job[i]) == 0) started[i] = 1; else tjf_run (&job[i]); }
-    }
-    tjf_run (&job[0]);
-    for (i = 1; i < nj; i++) if (started[i]) pthread_join (th[i], NULL);
-    t_parse += tjf_now () - tt; tt = tjf_now ();
+    pos = tjf_sequential (s, data, n, repair_from, wend, !whole_file);
+    s->t_parse += tjf_now () - tt;
+    return pos;
+  }
+  return job[nj - 1].end_pos;
+}
 
-    accepted = 0;
-    for (i = 0; i < nj; i++) {                          /* the chain of ranges: each must end where the next begins */
-      if (job[i].status == TJF_MISMATCH || job[i].status == TJF_OVERFLOW) break;
-      accepted++;
-      if (job[i].status == TJF_BADQUAL || job[i].status == TJF_EOF) { done = 1; break; }
-    }
-    if (accepted == nj || done) tjf_stat_windows++;      /* (the whole window came from the parallel readers) */
-    for (i = 0; i < accepted; i++) {
-      if (job[i].out_len && sink->put (sink->ctx, job[i].out, job[i].out_len, job[i].n_reads)) { done = 1; total_reads = -3; break; }
-      total_reads += job[i].n_reads;
-    }
-    if (total_reads >= 0 && sink->mark) { set_mark[set] = sink->mark (sink->ctx); if (set_mark[set] < 0) total_reads = -3; }
-    t_put += tjf_now () - tt;
-    if (total_reads < 0) break;
-    if (done) break;
-    if (accepted < nj) {                                /* inconsistent guess: one reader takes the rest of the file */
-      tjr_reader *r = tjr_open_mem (data, n, job[accepted].start);
-      const char *seq;
-      long len;
-      unsigned char *b = buf[set ^ 1][0];
-      size_t fill = 0;
-      long nr = 0;
-      fell_back = 1; tjf_stat_fallback = 1;
-      if (sink->sync && sink->sync (sink->ctx)) { total_reads = -3; tjr_close (r); break; }
-      while ((len = tjr_next (r, &seq)) >= 0) {
-        if ((size_t) len + 1 > cap) {                   /* longer than a buffer: on its own */
-          unsigned char *big = (unsigned char *) malloc ((size_t) len + 1);
-          memcpy (big, seq, (size_t) len); big[len] = '\n';
-          if (fill && sink->put (sink->ctx, b, fill, nr)) { total_reads = -3; free (big); break; }
-          total_reads += nr; fill = 0; nr = 0;
-          if (sink->put (sink->ctx, big, (size_t) len + 1, 1) || (sink->sync && sink->sync (sink->ctx))) { total_reads = -3; free (big); break; }
-          total_reads += 1;
-          free (big);
-          continue;
-        }
-        if (fill + (size_t) len + 1 > cap) {
-          if (sink->put (sink->ctx, b, fill, nr) || (sink->sync && sink->sync (sink->ctx))) { total_reads = -3; break; }
-          total_reads += nr; fill = 0; nr = 0;
-        }
-        memcpy (b + fill, seq, (size_t) len); b[fill + (size_t) len] = '\n';
-        fill += (size_t) len + 1; nr++;
-      }
-      if (total_reads >= 0 && fill) { if (sink->put (sink->ctx, b, fill, nr)) total_reads = -3; else total_reads += nr; }
-      tjr_close (r);
-      break;
-    }
-    pos = job[nj - 1].end_pos;
-    set ^= 1;
+static void
+tjf_trace (const tjf_state *s, const char *path, const char *kind, double t0, double t_inflate)
+{
+  if (!getenv ("TATAJUBA_AMD_FEEDER_TRACE")) return;
+  fprintf (stderr, "[feeder] %s (%s): %d threads, %ld windows%s, alloc %.1f ms, sync %.1f ms, parse %.1f ms, put %.1f ms, waiting for inflate %.1f ms, total %.1f ms\n",
+           path, kind, s->n_threads, tjf_stat_windows, tjf_stat_fallback ? " + one-reader repairs" : "", s->t_alloc * 1e3, s->t_sync * 1e3, s->t_parse * 1e3,
+           s->t_put * 1e3, t_inflate * 1e3, (tjf_now () - t0) * 1e3);
+}
+
+static const unsigned char *
+tjf_map (const char *path, size_t *n)
+{
+  struct stat st;
+  const unsigned char *data;
+  const int fd = open (path, O_RDONLY);
+  *n = 0;
+  if (fd < 0) return NULL;
+  if (fstat (fd, &st) != 0 || st.st_size < 0) { close (fd); return NULL; }
+  if (st.st_size == 0) { close (fd); return (const unsigned char *) ""; }
+  *n = (size_t) st.st_size;
+  data = (const unsigned char *) mmap (NULL, *n, PROT_READ, MAP_PRIVATE, fd, 0);
+  close (fd);
+  if (data == (const unsigned char *) MAP_FAILED) { *n = 0; return NULL; }
+  (void) madvise ((void *) data, *n, MADV_SEQUENTIAL);
+  return data;
+}
+
+long
+tjf_parse_file (const char *path, int n_threads, size_t window_bytes, const tjf_sink *sink)
+{
+  const unsigned char *data;
+  size_t n, pos = 0;
+  tjf_state s;
+  const double t0 = tjf_now ();
+  long total;
+
+  data = tjf_map (path, &n);
+  if (!data) return -1;
+  if (n == 0) return 0;
+  if (window_bytes < 4096) window_bytes = 4096;
+  tjf_stat_windows = 0; tjf_stat_fallback = 0; tjf_stat_bgzf = 0;
+  if (tjf_state_init (&s, sink, n_threads, window_bytes)) { tjf_state_free (&s); munmap ((void *) data, n); return -2; }
+  while (!s.done && pos < n) {
+    const size_t wend = (n - pos > window_bytes) ? pos + window_bytes : n;
+    pos = tjf_window (&s, data, n, pos, wend, 1);
   }
   if (sink->sync) (void) sink->sync (sink->ctx);
-  for (set = 0; set < 2; set++) for (i = 0; i < n_threads; i++) sink->release (sink->ctx, buf[set][i]);
+  tjf_state_free (&s);
   munmap ((void *) data, n);
-  if (trace) fprintf (stderr, "[feeder] %s: %d threads, %ld windows%s, alloc %.1f ms, sync %.1f ms, parse %.1f ms, put %.1f ms, total %.1f ms\n", path, n_threads,
-                      tjf_stat_windows, fell_back ? " + fallback" : "", t_alloc * 1e3, t_sync * 1e3, t_parse * 1e3, t_put * 1e3, (tjf_now () - t0) * 1e3);
-  (void) fell_back;
-  return total_reads;
+  tjf_trace (&s, path, "plain", t0, 0.0);
+  total = s.total_reads;
+  return total;
+}
+
+/* ---- gzip: inflate a view at a time --------------------------------------------------------------------------------
+ * gzip member (RFC 1952): 1f 8b, CM = 8, FLG, MTIME[4], XFL, OS, then optional FEXTRA / FNAME / FCOMMENT / FHCRC, the
+ * deflate stream, CRC32[4], ISIZE[4].  BGZF (the SAM specification, section 4.1; what bgzip writes) is a series of such members of
+ * at most 64 KiB of data each, every one with an FEXTRA subfield 'B','C',2,0 that holds the member's total size - 1:
+ * the members can be found without inflating anything and inflated independently. */
+
+typedef struct { size_t data_off, data_len, out_off; unsigned isize, crc; } tjz_block;
+
+typedef struct
+{
+  const unsigned char *z;
+  size_t zn, zpos;
+  int bgzf;             /* the members at zpos are BGZF blocks (until one is not) */
+  int ended;            /* nothing more will come (end of input, trailing garbage, damaged stream) */
+  int damaged;
+  z_stream strm;        /* the one-thread inflater (gzip wrapper), live across views */
+  int strm_open;
+  int n_threads;
+  tjz_block *blk;
+  size_t blk_cap;
+} tjz_source;
+
+/* a BGZF block header at p (avail bytes there)?  -> its total size, 0 if it is not one / not whole */
+static size_t
+tjz_bgzf_block (const unsigned char *p, size_t avail, size_t *data_off)
+{
+  size_t xlen, x, bsize = 0;
+  if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || p[3] != 4) return 0;   /* FLG == FEXTRA only, as bgzip writes it */
+  xlen = (size_t) p[10] | ((size_t) p[11] << 8);
+  if (12 + xlen > avail) return 0;
+  for (x = 12; x + 4 <= 12 + xlen; ) {
+    const size_t slen = (size_t) p[x + 2] | ((size_t) p[x + 3] << 8);
+    if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = ((size_t) p[x + 4] | ((size_t) p[x + 5] << 8)) + 1;
+    x += 4 + slen;
+  }
+  if (!bsize || bsize < 12 + xlen + 8 || bsize > avail) return 0;
+  *data_off = 12 + xlen;
+  return bsize;
+}
+
+typedef struct { tjz_source *src; unsigned char *out; size_t first, last; int bad_at_set; size_t bad_at; } tjz_job;
+
+static void *
+tjz_inflate_blocks (void *arg)
+{
+  tjz_job *j = (tjz_job *) arg;
+  z_stream zs;
+  size_t b;
+  memset (&zs, 0, sizeof zs);
+  j->bad_at_set = 0;
+  if (inflateInit2 (&zs, -15) != Z_OK) { j->bad_at_set = 1; j->bad_at = j->first; return NULL; }
+  for (b = j->first; b < j->last; b++) {
+    const tjz_block *k = &j->src->blk[b];
+    int rc;
+    if (k->isize == 0) continue;                        /* (the empty block bgzip ends a file with) */
+    inflateReset (&zs);
+    zs.next_in = (Bytef *) (j->src->z + k->data_off); zs.avail_in = (uInt) k->data_len;
+    zs.next_out = j->out + k->out_off; zs.avail_out = k->isize;
+    rc = inflate (&zs, Z_FINISH);
+    if (rc != Z_STREAM_END || zs.avail_out != 0 || (unsigned) crc32 (crc32 (0L, Z_NULL, 0), j->out + k->out_off, k->isize) != k->crc) {
+      j->bad_at_set = 1; j->bad_at = b; break;
+    }
+  }
+  inflateEnd (&zs);
+  return NULL;
+}
+
+/* the next inflated bytes of the file into out[0, cap) (cap >= 64 KiB); 0 only when nothing is left */
+static size_t
+tjz_fill (tjz_source *s, unsigned char *out, size_t cap)
+{
+  size_t got = 0;
+  while (!s->ended && got < cap) {
+    if (s->zpos >= s->zn) { s->ended = 1; if (s->strm_open) s->damaged = 1; break; }   /* (inside a member: truncated) */
+    if (s->bgzf && !s->strm_open) {                     /* gather whole blocks that fit, inflate them side by side */
+      size_t nb = 0, zp = s->zpos, off = got;
+      int nt, t;
+      pthread_t th[TJF_MAX_THREADS];
+      tjz_job job[TJF_MAX_THREADS];
+      int started[TJF_MAX_THREADS];
+      for (;;) {
+        size_t doff, bsize;
+        unsigned isize;
+        if (zp >= s->zn) break;
+        bsize = tjz_bgzf_block (s->z + zp, s->zn - zp, &doff);
+        if (!bsize) { if (!nb) s->bgzf = 0; break; }    /* something else from here on: the general inflater takes it */
+        isize = (unsigned) s->z[zp + bsize - 4] | ((unsigned) s->z[zp + bsize - 3] << 8) | ((unsigned) s->z[zp + bsize - 2] << 16) | ((unsigned) s->z[zp + bsize - 1] << 24);
+        if (isize > 65536u) { if (!nb) s->bgzf = 0; break; }
+        if (off + isize > cap) break;
+        if (nb == s->blk_cap) {
+          s->blk_cap = s->blk_cap ? 2 * s->blk_cap : 4096;
+          s->blk = (tjz_block *) realloc (s->blk, s->blk_cap * sizeof (tjz_block));
+        }
+        s->blk[nb].data_off = zp + doff; s->blk[nb].data_len = bsize - doff - 8; s->blk[nb].out_off = off; s->blk[nb].isize = isize;
+        s->blk[nb].crc = (unsigned) s->z[zp + bsize - 8] | ((unsigned) s->z[zp + bsize - 7] << 8) | ((unsigned) s->z[zp + bsize - 6] << 16) | ((unsigned) s->z[zp + bsize - 5] << 24);
+        nb++; off += isize; zp += bsize;
+      }
+      if (!nb) { if (s->bgzf) break; else continue; }   /* (bgzf still set: the next block does not fit -- the view is full) */
+      nt = s->n_threads; if ((size_t) nt > nb) nt = (int) nb;
+      for (t = 0; t < nt; t++) {
+        job[t].src = s; job[t].out = out; job[t].first = nb * (size_t) t / (size_t) nt; job[t].last = nb * (size_t) (t + 1) / (size_t) nt;
+        started[t] = 0;
+        if (t) { if (pthread_create (&th[t], NULL, tjz_inflate_blocks, &job[t]) == 0) started[t] = 1; else tjz_inflate_blocks (&job[t]); }
+      }
+      tjz_inflate_blocks (&job[0]);
+      for (t = 1; t < nt; t++) if (started[t]) pthread_join (th[t], NULL);
+      tjf_stat_bgzf += (long) nb;
+      for (t = 0; t < nt; t++) if (job[t].bad_at_set) {  /* a damaged block: the file ends in front of it */
+        const size_t b = job[t].bad_at;
+        off = s->blk[b].out_off; s->ended = 1; s->damaged = 1;
+        break;
+      }
+      got = off; s->zpos = zp;
+      continue;
+    }
+    /* any other gzip stream: one inflater, members one after the other (what gzread does: zlib's gzread.c gz_look /
+     * gz_decomp -- another member if the next two bytes are 1f 8b, anything else after a member is ignored) */
+    if (!s->strm_open) {
+      memset (&s->strm, 0, sizeof s->strm);
+      if (inflateInit2 (&s->strm, 15 + 16) != Z_OK) { s->ended = 1; s->damaged = 1; break; }
+      s->strm_open = 1;
+    }
+    {
+      const size_t in_now = (s->zn - s->zpos > (1u << 30)) ? (1u << 30) : s->zn - s->zpos;
+      const size_t out_now = (cap - got > (1u << 30)) ? (1u << 30) : cap - got;
+      int rc;
+      s->strm.next_in = (Bytef *) (s->z + s->zpos); s->strm.avail_in = (uInt) in_now;
+      s->strm.next_out = out + got; s->strm.avail_out = (uInt) out_now;
+      rc = inflate (&s->strm, Z_NO_FLUSH);
+      s->zpos += in_now - s->strm.avail_in;
+      got += out_now - s->strm.avail_out;
+      if (rc == Z_STREAM_END) {
+        inflateEnd (&s->strm); s->strm_open = 0;
+        if (s->zn - s->zpos < 2 || s->z[s->zpos] != 0x1f || s->z[s->zpos + 1] != 0x8b) s->ended = 1;
+        else { size_t d; s->bgzf = tjz_bgzf_block (s->z + s->zpos, s->zn - s->zpos, &d) != 0; }
+      }
+      else if (rc == Z_OK) { if (in_now == s->strm.avail_in && out_now == s->strm.avail_out) { s->ended = 1; s->damaged = 1; } }
+      else { s->ended = 1; s->damaged = 1; }
+    }
+  }
+  return got;
+}
+
+typedef struct { tjz_source *src; unsigned char *out; size_t cap, got; } tjz_fill_job;
+static void *tjz_fill_thread (void *arg) { tjz_fill_job *f = (tjz_fill_job *) arg; f->got = tjz_fill (f->src, f->out, f->cap); return NULL; }
+
+long
+tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const tjf_sink *sink)
+{
+  tjz_source src;
+  tjf_state s;
+  unsigned char *view[2] = {NULL, NULL};
+  size_t view_cap[2] = {0, 0}, head[2];                 /* view[i] holds payload at [head[i], head[i] + got) */
+  size_t reserve = 1u << 20, payload;
+  tjz_fill_job fj;
+  pthread_t fth;
+  int cur = 0, fill_running = 0, fill_threaded = 0;
+  size_t carry_len = 0;
+  const double t0 = tjf_now ();
+  double t_inflate = 0, tt;
+  long total;
+
+  memset (&src, 0, sizeof src);
+  src.z = tjf_map (path, &src.zn);
+  if (!src.z) return -1;
+  if (src.zn < 2 || src.z[0] != 0x1f || src.z[1] != 0x8b) { if (src.zn) munmap ((void *) src.z, src.zn); return -1; }
+  if (window_bytes < 65536) window_bytes = 65536;       /* a BGZF block must fit */
+  payload = window_bytes;
+  if (reserve > payload) reserve = payload;
+  { size_t d; src.bgzf = tjz_bgzf_block (src.z, src.zn, &d) != 0; }
+  src.n_threads = n_threads < 1 ? 1 : (n_threads > TJF_MAX_THREADS ? TJF_MAX_THREADS : n_threads);
+  tjf_stat_windows = 0; tjf_stat_fallback = 0; tjf_stat_bgzf = 0;
+  if (tjf_state_init (&s, sink, n_threads, window_bytes + reserve)) { tjf_state_free (&s); munmap ((void *) src.z, src.zn); return -2; }
+  for (cur = 0; cur < 2; cur++) {
+    view_cap[cur] = reserve + payload; head[cur] = reserve;
+    view[cur] = (unsigned char *) malloc (view_cap[cur]);
+    if (!view[cur]) { s.total_reads = -2; s.done = 1; }
+  }
+  cur = 0;
+  if (!s.done) { fj.src = &src; fj.out = view[0] + head[0]; fj.cap = payload; fj.got = tjz_fill (&src, fj.out, fj.cap); }
+  while (!s.done) {
+    /* view `cur`: carry_len bytes in front of head[cur] (already in place) + fj.got fresh bytes */
+    unsigned char *v = view[cur] + head[cur] - carry_len;
+    const size_t n = carry_len + fj.got;
+    const int final = src.ended;                        /* (the producer is not running here) */
+    const int nxt = cur ^ 1;
+    size_t pos;
+    if (n == 0) break;
+    if (!final) {                                       /* the producer fills the other view while this one is parsed */
+      fj.src = &src; fj.out = view[nxt] + head[nxt]; fj.cap = view_cap[nxt] - head[nxt]; fj.got = 0;
+      fill_threaded = pthread_create (&fth, NULL, tjz_fill_thread, &fj) == 0;
+      fill_running = 1;
+    }
+    pos = tjf_window (&s, v, n, 0, n, final);
+    if (final) break;
+    tt = tjf_now ();
+    if (fill_threaded) pthread_join (fth, NULL); else tjz_fill_thread (&fj);
+    fill_running = 0;
+    t_inflate += tjf_now () - tt;
+    if (s.done) break;
+    carry_len = n - pos;                                /* the cut record: in front of the fresh bytes of the other view */
+    if (carry_len > head[nxt]) {                        /* (a record longer than the room in front: a bigger view) */
+      const size_t new_head = carry_len + reserve, new_cap = new_head + (view_cap[nxt] - head[nxt]) + carry_len;
+      unsigned char *bigger = (unsigned char *) malloc (new_cap);
+      if (!bigger) { s.total_reads = -2; break; }
+      memcpy (bigger + new_head, view[nxt] + head[nxt], fj.got);
+      free (view[nxt]); view[nxt] = bigger; view_cap[nxt] = new_cap; head[nxt] = new_head;
+    }
+    memcpy (view[nxt] + head[nxt] - carry_len, v + pos, carry_len);
+    cur = nxt;
+  }
+  if (fill_running) { if (fill_threaded) pthread_join (fth, NULL); }
+  if (sink->sync) (void) sink->sync (sink->ctx);
+  if (src.damaged) fprintf (stderr, "tatajuba_amd: '%s' is truncated or damaged; reading stops where its gzip stream breaks\n", path);
+  if (src.strm_open) inflateEnd (&src.strm);
+  free (src.blk);
+  free (view[0]); free (view[1]);
+  tjf_state_free (&s);
+  munmap ((void *) src.z, src.zn);
+  tjf_trace (&s, path, tjf_stat_bgzf ? "bgzf" : "gzip", t0, t_inflate);
+  total = s.total_reads;
+  return total;
 }

@@ -1,4 +1,4 @@
-/* feeder.h -- multi-threaded host feeder for plain FASTA/FASTQ files; see feeder.c. */
+/* feeder.h -- multi-threaded host feeder for FASTA/FASTQ files (plain, gzip, BGZF); see feeder.c. */
 #ifndef TATAJUBA_AMD_FEEDER_H
 #define TATAJUBA_AMD_FEEDER_H
 #include <stddef.h>
@@ -23,7 +23,12 @@ int tjf_is_plain_file (const char *path);
  * the sink, -1 if the file cannot be opened / mapped, -2 out of memory, -3 if the sink failed. */
 long tjf_parse_file (const char *path, int n_threads, size_t window_bytes, const tjf_sink *sink);
 
-/* diagnostics of the last call in this process: windows accepted from the parallel readers, 1 if one reader had to take over */
+/* The same for a gzip file (first two bytes 1f 8b): a producer thread inflates one view of window_bytes ahead of the
+ * parse -- BGZF members by n_threads threads side by side, any other gzip stream by one.  Same return values. */
+long tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const tjf_sink *sink);
+long tjf_last_bgzf_blocks (void);                           /* BGZF members the last call inflated side by side */
+
+/* diagnostics of the last call in this process: windows that came whole from the parallel readers, windows that one reader had to finish */
 void tjf_last_stats (long *windows, long *fell_back);
 
 #endif

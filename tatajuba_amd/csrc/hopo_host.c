@@ -185,6 +185,8 @@ tj_feeder_threads (void)
 
 #define TJ_FEEDER_MIN_BYTES (32l << 20)                  /* smaller files: one reader is as fast */
 #define TJ_FEEDER_WINDOW    (128l << 20)
+#define TJ_FEEDER_MIN_GZ_BYTES (4l << 20)                /* gzip: the inflate runs ahead of the parse from this size on */
+#define TJ_FEEDER_GZ_WINDOW (64l << 20)                  /* inflated bytes per view */
 
 /* ---- file -> device (reference: src/hopo_counter.c:135-157) -------------------------------------------------------- */
 
@@ -207,18 +209,21 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
     h->opt = opt;
   }
   if (h->idx_initial) tj_fatal ("This counter has been compared to another; cannot add more reads to it"); /* reference :152 */
-  {                                                     /* big uncompressed file: several readers (feeder.c), same output */
+  {                                                     /* big file: several readers / inflaters (feeder.c), same output */
     struct stat st;
     const int threads = tj_feeder_threads ();
-    if (threads > 1 && tjf_is_plain_file (filename) == 1 && stat (filename, &st) == 0 && st.st_size >= TJ_FEEDER_MIN_BYTES) {
+    const int plain = threads > 1 ? tjf_is_plain_file (filename) : -1;
+    if (plain >= 0 && stat (filename, &st) == 0 && st.st_size >= (plain ? TJ_FEEDER_MIN_BYTES : TJ_FEEDER_MIN_GZ_BYTES)) {
       tj_gpu_sink g;
       tjf_sink sk;
       long got;
       g.dev = tj_device_counter (h); g.min_tract_size = opt.min_tract_size;
       sk.ctx = &g; sk.alloc = tj_sink_alloc; sk.release = tj_sink_release; sk.put = tj_sink_put; sk.sync = tj_sink_sync;
       sk.mark = tj_sink_mark; sk.wait = tj_sink_wait;
-      (void) tjamd_reserve (g.dev, (size_t) st.st_size / 2, opt.min_tract_size);   /* about half of a FASTQ file is sequence */
-      got = tjf_parse_file (filename, threads, (size_t) TJ_FEEDER_WINDOW, &sk);
+      /* about half of a FASTQ file is sequence; gzip packs it about four times smaller */
+      (void) tjamd_reserve (g.dev, plain ? (size_t) st.st_size / 2 : (size_t) st.st_size * 2, opt.min_tract_size);
+      got = plain ? tjf_parse_file (filename, threads, (size_t) TJ_FEEDER_WINDOW, &sk)
+                  : tjf_parse_gz_file (filename, threads, (size_t) TJ_FEEDER_GZ_WINDOW, &sk);
       if (got == -2 || got == -3) tj_fatal ("%s", got == -2 ? "out of pinned host memory for the feeder" : tjamd_last_error ());
       if (got >= 0) {
         n = tjamd_raw_count (g.dev);
@@ -299,8 +304,10 @@ tjamd_read_file_stream_mt (const char *path, unsigned char *out, long capacity, 
   tj_mem_sink m = {out, capacity, 0, 0};
   tjf_sink sk = {&m, tj_mem_alloc, tj_mem_release, tj_mem_put, NULL, NULL, NULL};
   long got;
-  if (tjf_is_plain_file (path) != 1) return tjamd_read_file_stream (path, out, capacity, n_reads);
-  got = tjf_parse_file (path, n_threads, (size_t) (window_bytes > 0 ? window_bytes : TJ_FEEDER_WINDOW), &sk);
+  const int plain = tjf_is_plain_file (path);
+  if (plain < 0) return -1;
+  got = plain ? tjf_parse_file (path, n_threads, (size_t) (window_bytes > 0 ? window_bytes : TJ_FEEDER_WINDOW), &sk)
+              : tjf_parse_gz_file (path, n_threads, (size_t) (window_bytes > 0 ? window_bytes : TJ_FEEDER_GZ_WINDOW), &sk);
   if (got < 0) return -1;
   if (n_reads) *n_reads = m.n_reads;
   return m.total;
@@ -308,6 +315,7 @@ tjamd_read_file_stream_mt (const char *path, unsigned char *out, long capacity, 
 
 /* diagnostic (not in the public header): windows the feeder accepted in its last call, and whether it fell back */
 long tjamd_debug_feeder_stats (long *fell_back) { long w = 0; tjf_last_stats (&w, fell_back); return w; }
+long tjamd_debug_feeder_bgzf_blocks (void) { return tjf_last_bgzf_blocks (); }
 
 /* ---- one sequence, synchronously (reference: src/hopo_counter.c:219-258) ------------------------------------------ */
 

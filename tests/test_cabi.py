@@ -207,13 +207,16 @@ def test_feeder_matches_single_reader_on_adversarial_files(tmp_path, seed):
         assert n == m and got.tobytes() == exp.tobytes(), (seed, threads, window)
 
 
-def test_feeder_really_runs_in_parallel_on_ordinary_fastq(tmp_path):
+@pytest.mark.parametrize("quals", ["@", "#-27<AFI@>+"])
+def test_feeder_really_runs_in_parallel_on_ordinary_fastq(tmp_path, quals):
     import ctypes as C
     from tatajuba_amd.capi import read_file_stream_mt
     rng = np.random.default_rng(4)
     reads = ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(20000)]
     p = str(tmp_path / "plain.fq")
-    _write(p, "".join(f"@read{i} 1:N:0\n{r}\n+\n{'@' * 150}\n" for i, r in enumerate(reads)))   # worst-case qualities
+    # worst-case qualities: lines that begin with '@', '>' (Phred 29) or '+' like the lines that structure the file
+    q = np.frombuffer(quals.encode(), np.uint8)[rng.integers(0, len(quals), size=(20000, 150))]
+    _write(p, "".join(f"@read{i} 1:N:0\n{r}\n+\n{q[i].tobytes().decode()}\n" for i, r in enumerate(reads)))
     got, n = read_file_stream_mt(p, 8, 1 << 20)
     assert n == 20000 and got.tobytes() == ("\n".join(reads) + "\n").encode()
     L = tj.lib()
@@ -239,6 +242,110 @@ def test_feeder_long_records_and_gzip_passthrough(tmp_path):
     got, n = read_file_stream_mt(g, 4, 4096)
     exp, m = tj.read_file_stream(g)
     assert n == m == 200 and got.tobytes() == exp.tobytes()
+
+
+# ---- gzip input through the feeder: inflate runs ahead of the parse; BGZF members are inflated side by side -------------
+
+def _gzip_member(data, extra=None, level=6):
+    """one RFC 1952 member around `data`; extra = callable(total_size_without_extra_known) is not needed: BGZF's BC
+    subfield holds the member's size - 1, which is known once the deflate stream is"""
+    import struct, zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = co.compress(data) + co.flush()
+    tail = struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+    if extra is None:
+        return b"\x1f\x8b\x08\x00" + b"\0" * 4 + b"\x00\xff" + body + tail
+    total = 12 + 6 + len(body) + 8                          # header(10) + XLEN(2) + BC subfield(6) + stream + CRC/ISIZE
+    return b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, total - 1) + body + tail
+
+
+def _bgzf(data, block=0xff00, eof=True):
+    out = [_gzip_member(data[i:i + block], extra="BC") for i in range(0, len(data), block)]
+    if eof:
+        out.append(_gzip_member(b"", extra="BC"))
+    return b"".join(out)
+
+
+def _check_gz(path, raw_text_path, combos):
+    from tatajuba_amd.capi import read_file_stream_mt
+    exp, m = tj.read_file_stream(path)                      # one reader over zlib's gzread, as the reference reads it
+    if raw_text_path is not None:
+        ora, mo = orc.parse_file_to_stream(raw_text_path)
+        assert mo == m and ora.tobytes() == exp.tobytes()
+    for threads, window in combos:
+        got, n = read_file_stream_mt(path, threads, window)
+        assert n == m and got.tobytes() == exp.tobytes(), (path, threads, window)
+    return m
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_gzip_feeder_matches_gzread_on_adversarial_files(tmp_path, seed):
+    import ctypes as C, gzip
+    rng = np.random.default_rng(seed)
+    txt = _adversarial_file(rng, 5000).encode()
+    raw = str(tmp_path / "adv.fq")
+    open(raw, "wb").write(txt)
+    combos = [(1, 65536), (2, 65536), (5, 100000), (8, 1 << 20), (3, 1 << 30)]
+    L = tj.lib()
+    L.tjamd_debug_feeder_bgzf_blocks.restype = C.c_long
+    # (a) one member, as gzip(1) writes it
+    p = str(tmp_path / "one.fq.gz")
+    open(p, "wb").write(gzip.compress(txt, 6))
+    m = _check_gz(p, raw, combos)
+    assert m > 1000 and L.tjamd_debug_feeder_bgzf_blocks() == 0
+    # (b) BGZF, as bgzip writes it (with and without the empty last block)
+    for eof in (True, False):
+        p = str(tmp_path / f"bgzf{int(eof)}.fq.gz")
+        open(p, "wb").write(_bgzf(txt, eof=eof))
+        assert _check_gz(p, raw, combos) == m
+        assert L.tjamd_debug_feeder_bgzf_blocks() >= len(txt) // 0xff00
+    # (c) members glued together: plain ones, then BGZF blocks, then a plain one again; small odd-sized BGZF blocks
+    cut1, cut2 = len(txt) // 3, 2 * len(txt) // 3
+    p = str(tmp_path / "mixed.fq.gz")
+    open(p, "wb").write(gzip.compress(txt[:cut1 // 2]) + _gzip_member(txt[cut1 // 2:cut1]) + _bgzf(txt[cut1:cut2], block=1234, eof=False) + gzip.compress(txt[cut2:]))
+    assert _check_gz(p, raw, combos) == m
+    assert L.tjamd_debug_feeder_bgzf_blocks() >= (cut2 - cut1) // 1234 - 1
+    # (d) bytes that are not gzip after the last member are ignored, as gzread ignores them
+    p = str(tmp_path / "trail.fq.gz")
+    open(p, "wb").write(gzip.compress(txt) + b"\0\0\0\0garbage")
+    assert _check_gz(p, raw, combos[:2]) == m
+
+
+def test_gzip_feeder_records_longer_than_a_view_and_bad_quality(tmp_path):
+    import gzip
+    rng = np.random.default_rng(31)
+    long_seq = "".join(rng.choice(list("ACGT"), size=300000))
+    txt = (">chr1\n" + "\n".join(long_seq[i:i + 60] for i in range(0, len(long_seq), 60)) + "\n" + CASES["fastq4"] * 300
+           + "@long\n" + long_seq + "\n+\n" + "I" * len(long_seq) + "\n" + CASES["fastq4"] * 300 + ">chr2\n" + long_seq).encode()   # no newline at the end
+    raw = str(tmp_path / "long.fa")
+    open(raw, "wb").write(txt)
+    for name, blob in (("one", gzip.compress(txt)), ("bgzf", _bgzf(txt))):
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(blob)
+        assert _check_gz(p, raw, [(4, 65536), (2, 100000), (4, 1 << 22)]) == 1203
+    # a bad quality string in the middle ends the file there for every reader
+    bad = (CASES["fastq4"] * 2000 + "@bad\nACGTACGTA\n+\nIII\n" + CASES["fastq4"] * 2000).encode()
+    raw = str(tmp_path / "bad.fq")
+    open(raw, "wb").write(bad)
+    p = str(tmp_path / "bad.fq.gz")
+    open(p, "wb").write(_bgzf(bad, block=5000))
+    m = _check_gz(p, raw, [(4, 65536), (3, 70000)])
+    assert 4000 <= m <= 4001
+
+
+def test_gzip_feeder_truncated_file_stops_where_the_stream_breaks(tmp_path):
+    import gzip
+    from tatajuba_amd.capi import read_file_stream_mt
+    rng = np.random.default_rng(41)
+    reads = ["".join(rng.choice(list("ACGT"), size=100)) for _ in range(20000)]
+    txt = "".join(f"@r{i}\n{r}\n+\n{'I' * 100}\n" for i, r in enumerate(reads)).encode()
+    whole = "\n".join(reads) + "\n"
+    for name, blob in (("one", gzip.compress(txt)), ("bgzf", _bgzf(txt))):
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(blob[: len(blob) * 2 // 3])
+        got, n = read_file_stream_mt(p, 4, 65536)
+        assert 5000 < n < 20000                            # what could be inflated is read, complete records only ...
+        assert whole.startswith(got.tobytes().decode()[: -102] if n else "")   # ... and it is a prefix of the file's reads
 
 
 def test_fixture_file_stream(golden_dir, known_answers):

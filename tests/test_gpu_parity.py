@@ -473,6 +473,39 @@ def test_dropin_large_file_batches(tmp_path):
     h.delete()
 
 
+@pytest.mark.parametrize("kind", ["gzip", "bgzf"])
+def test_dropin_gzip_files_through_the_feeder(tmp_path, monkeypatch, kind):
+    # a .fastq.gz of more than 4 MiB: inflated a window ahead of the parse (BGZF: members side by side), same counter
+    import ctypes as C
+    import gzip
+    from tests.test_cabi import _bgzf
+    monkeypatch.setenv("TATAJUBA_AMD_FEEDER_THREADS", "6")
+    s = tj.synth_stream(120000, 150, 1000000)
+    reads = bytes(s).split(b"\n")[:-1]
+    rng = np.random.default_rng(8)
+    q = np.frombuffer(b"#-27<AFI@>+", np.uint8)[rng.integers(0, 11, size=150 * len(reads))].tobytes()
+    txt = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, q[150 * i:150 * i + 150]) for i, r in enumerate(reads))
+    p = str(tmp_path / (kind + ".fq.gz"))
+    with open(p, "wb") as fh:
+        fh.write(gzip.compress(txt, 1) if kind == "gzip" else _bgzf(txt))
+    assert os.path.getsize(p) > (4 << 20)
+    opt = tj.Options.defaults(10, 3, 3, True)
+    h = tj.HopoCounter.new_or_append_from_file(None, p, opt)
+    L = tj.lib()
+    L.tjamd_debug_feeder_stats.restype = C.c_long
+    L.tjamd_debug_feeder_bgzf_blocks.restype = C.c_long
+    fb = C.c_long(-1)
+    assert L.tjamd_debug_feeder_stats(C.byref(fb)) >= 1 and fb.value == 0
+    assert (L.tjamd_debug_feeder_bgzf_blocks() > 500) == (kind == "bgzf")
+    o = orc.Oracle(10)
+    o.scan_stream(s, 3)
+    assert h.c.n_elem == o.c.n_elem
+    h.finalise()
+    o.finalise(1, 3)
+    assert h.elems().tobytes() == o.elems().tobytes() and h.c.coverage == o.c.coverage
+    h.delete()
+
+
 def test_dropin_plain_fastq_through_the_multithreaded_feeder(tmp_path, monkeypatch):
     # an uncompressed FASTQ of > 32 MiB goes through feeder.c (several readers over the mapped file); quality strings
     # that look like headers make its range-start guesses work for their living
