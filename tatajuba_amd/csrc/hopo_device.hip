@@ -230,6 +230,23 @@ __device__ __forceinline__ void lds_barrier ()
   asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+// LDS atomic add of a wave-uniform value by the wave's first lane alone, result left in flight: *raw_out (lane 0) holds
+// the old value once lgkmcnt has drained (lds_collect).  Hand-written because the compiler's version of "one lane adds
+// for the wave" costs a dozen scalar instructions, which on this chip are no cheaper than vector ones.
+__device__ __forceinline__ void lds_add_issue (u32 lds_addr, u32 value_uniform, u32 &raw_out)
+{
+  u64 saved; u32 tmp;
+  asm volatile ("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tv_mov_b32 %1, %4\n\tds_add_rtn_u32 %2, %3, %1\n\ts_mov_b64 exec, %0"
+                : "=&s"(saved), "=&v"(tmp), "=&v"(raw_out) : "v"(lds_addr), "s"(value_uniform) : "memory");
+}
+__device__ __forceinline__ u32 lds_collect (u32 raw)
+{
+  asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(raw) :: "memory");
+  return (u32) __builtin_amdgcn_readfirstlane ((int) raw);
+}
+
 // 64 bits of a little-endian bit array starting at bit position `bitpos` (array padded by >= 2 words)
 __device__ __forceinline__ u64 bits64 (const u32 *a, int bitpos)
 {
@@ -362,8 +379,6 @@ __device__ __forceinline__ void emit_record (bool have, u64 c0, u64 c1, u64 meta
 // lane; lane l's 16 bytes land at lds_wave_base + l.  A chunk that sticks out of the stream reads the stream's first
 // bytes instead and is rebuilt bytewise when it is consumed.  Requires >= 16 readable bytes at seq (the host pads tiny
 // streams).
-typedef __attribute__((address_space(1))) const void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
 
 // The LDS-DMA instruction itself, from inline assembly.  Through the builtin the compiler knows that a VMEM operation
 // writes LDS and, unable to tell where, waits for it (s_waitcnt vmcnt(0): the prefetch AND every bucket store in
@@ -815,7 +830,10 @@ __device__ __forceinline__ u32 bucket_of_rec1 (u32 lo, u32 hi)
 
 #define TJ_P        256                 // hash buckets
 #define TJ_PBITS    8
-#define TJ_STAGE_WORDS 2048             // 64-bit words of one-word records a workgroup stages in LDS between partition passes (twice that in the fast kernel)
+#ifndef TJ_STAGE_WORDS
+#define TJ_STAGE_WORDS 2048
+#endif
+// TJ_STAGE_WORDS: 64-bit words of one-word records a workgroup stages in LDS between partition passes (twice that in the fast kernel)
 #define TJ_CH0      1536                // chunk size unit in records; chunks are TJ_CH0 << ch_shift with ch_shift >= 2
 #define TJ_EMPTY    0xFFFFFFFFu
 
@@ -969,6 +987,21 @@ struct StageSink
       L.rec[at * WS] = ((u64) hi << 32) | lo;             // (W == 1)
       L.bin[at] = (unsigned char) bucket_of_rec1 (lo, hi);
     }
+  }
+
+  // the same in two steps, so that the slot's atomic is in flight while the caller works the record out:
+  // reserve1 (round_max) by everybody; then per wave: lds_add_issue (count_addr (), records of the wave, raw); ...;
+  // at = lds_collect (raw) + rank in the wave; if (have) store1 (at, lo, hi);
+  __device__ __forceinline__ void reserve1 (u32 round_max)
+  {
+    if (bound + round_max > (u32) S) { partition (); bound = 0; }
+    bound += round_max;
+  }
+  __device__ __forceinline__ u32 count_addr () const { return (u32) (size_t) (lptr_t) &L.n; }
+  __device__ __forceinline__ void store1 (u32 at, u32 lo, u32 hi)
+  {
+    L.rec[at * WS] = ((u64) hi << 32) | lo;
+    L.bin[at] = (unsigned char) bucket_of_rec1 (lo, hi);
   }
 
   __device__ __forceinline__ void partition ()
@@ -1188,13 +1221,19 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
 // one of the code plane per flank.
 
 #define FK_BLOCK    512
-#define FK_WG_PER_CU 2                  // 73 KB of LDS each (the 4096-record staging buffer is worth more than a third workgroup)
+#ifndef FK_WG_PER_CU
+#define FK_WG_PER_CU 2
+#endif
+// FK_WG_PER_CU: 73 KB of LDS each (the 4096-record staging buffer is worth more than a third workgroup)
 #define FK_UNIT     32                  // stream bytes per lane
 #define FK_WIN      (FK_BLOCK * FK_UNIT)
 #define FK_HL       32
 #define FK_HR       64
 #define FK_OWN      (FK_WIN - FK_HL - FK_HR)
-#define FK_MAXCAND  4096                // (a tile with more candidates goes to the generic kernel: more than one per 4 positions)
+#ifndef FK_MAXCAND
+#define FK_MAXCAND  4096
+#endif
+// FK_MAXCAND: (a tile with more candidates goes to the generic kernel: more than one per 4 positions)
 #define FK_GROUP    8                   // tiles per work-counter atomic
 
 struct FastLds
@@ -1287,6 +1326,16 @@ __device__ __noinline__ u64 fast_general_tract (const FastLds &T, const uint8_t 
   return pack_rec1 ((u32) c0, (u32) c1, base, len10, flag);
 }
 
+// two LDS-DMA loads of 1 KiB each (lane l: 16 bytes at sbase + voff, voff = 16 l) with a wave-uniform base address in
+// SGPRs and one M0 write: the instruction offset of the second load moves its global address and its LDS address alike
+__device__ __forceinline__ void lds_dma32 (const uint8_t *sbase, u32 voff, void *lds_wave_base)
+{
+  const u32 m0v = (u32) (size_t) (lptr_t) lds_wave_base;
+  u32 saved;                                            // (M0 is the compiler's: put it back)
+  asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                : "=&s"(saved) : "v"(voff), "s"(sbase), "s"(m0v) : "memory");
+}
+
 template <int W>
 __global__ __launch_bounds__ (FK_BLOCK, FK_BLOCK * FK_WG_PER_CU / 256)
 void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_ftiles, int k, int mprime,
@@ -1294,8 +1343,11 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 {
   __shared__ FastLds T;
   __shared__ uint4 raw[FK_WIN / 16];
-  __shared__ StageLds<W, W == 1> SL;
-  StageSink<W, FK_BLOCK, W == 1> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
+#ifndef FK_BIG
+#define FK_BIG (W == 1)
+#endif
+  __shared__ StageLds<W, FK_BIG> SL;
+  StageSink<W, FK_BLOCK, FK_BIG> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
   sink.start ();
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1314,57 +1366,66 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   asm ("v_mov_b32 %0, 32" : "=v"(v32));
   asm ("v_mov_b32 %0, %1" : "=v"(vmp) : "s"(mprime));
   const u32 own = (tid == 0 || tid >= (FK_WIN - FK_HR) / FK_UNIT) ? 0u : 0xFFFFFFFFu;   // halo lanes own no tract start
+  const u32 voff16 = 16u * (u32) lane;
 
-  if (tid == 0) {
-    T.grp[0] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP);
-    if (blockIdx.x == 0) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; }
+  // Scalar instructions are not free on this chip (about 4.6 cycles each per SIMD, tools/ubench/valu_salu.hip), so the
+  // loop's bookkeeping is kept to 32-bit scalars: a launch covers less than 2 GiB (scan_device_piece), tile numbers and
+  // byte offsets fit an int.  Tiles 1 .. t_hi have their whole window (and the 16 bytes in front) inside the stream.
+  const int nt_all = (int) n_ftiles, nb = (int) n_bytes;
+  const int t_hi = (nb >= FK_WIN - FK_HL) ? (nb - (FK_WIN - FK_HL)) / FK_OWN : 0;
+  const bool fast_any = !all_slow;
+  const u32 ncand_addr = (u32) (size_t) (lptr_t) &T.ncand[0];
+
+  if (wave == 0) {
+    if (lane == 0) {
+      T.grp[0] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP);
+      if (blockIdx.x == 0) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; }
+    }
+    if (lane < 4) { T.ncand[lane] = 0; T.bad[lane] = 0; T.code[FK_WIN / 16 + lane] = 0; T.st[FK_WIN / 32 + lane] = 0; T.lt[FK_WIN / 32 + lane] = 0; }
   }
-  if (tid < 4) { T.ncand[tid] = 0; T.bad[tid] = 0; T.code[FK_WIN / 16 + tid] = 0; T.st[FK_WIN / 32 + tid] = 0; T.lt[FK_WIN / 32 + tid] = 0; }
+  // (phase 3 reads the candidate list with a clamped index instead of a branch: every entry must be a position)
+  for (int i = tid; i < FK_MAXCAND + 2; i += FK_BLOCK) T.cand[i] = (unsigned short) FK_HL;
   lds_barrier ();
-  long tile = (long) T.grp[0];
-  long grp_end = tile + FK_GROUP;
+  int tile = __builtin_amdgcn_readfirstlane ((int) T.grp[0]);
+  int grp_end = tile + FK_GROUP;
   u32 gpar = 0, it = 0;
 
-  // A tile whose window (and the four bytes in front of it) lies inside the stream takes the straight path; the
-  // stream's first and last tiles are done here too: their chunks that stick out are fetched from a valid address
-  // instead and phase 1 overwrites what lies outside the stream with read delimiters (edge_words).
-  auto interior = [&] (long t) { const long g = t * (long) FK_OWN - FK_HL; return g >= 16 && g + (long) FK_WIN <= n_bytes; };
-  auto taken = [&] (long t) { return !all_slow; };
   // next tile's bytes: HBM -> LDS, 2 KiB per wave (two instructions of 1 KiB), and the word in front of the wave's
-  // first byte
+  // first byte.  The stream's first and last tiles are done here too: their chunks that stick out are fetched from a
+  // valid address instead and phase 1 overwrites what lies outside the stream with read delimiters (edge_chunk).
   u32 pred = 0;
-  auto prefetch = [&] (long t) {
-    const long g0w = (t * (long) FK_OWN - FK_HL) + 2048l * wave;          // stream position of the wave's first byte
-    if (interior (t)) {
+  auto prefetch = [&] (int t) {
+    const int g0w = t * FK_OWN - FK_HL + 2048 * wave;   // stream position of the wave's first byte
+    if (t >= 1 && t <= t_hi) {
       const uint8_t *g = seq + g0w;
-      lds_dma16 (g + 16l * lane, &raw[128 * wave]);
-      lds_dma16 (g + 1024l + 16l * lane, &raw[128 * wave + 64]);
+      lds_dma32 (g, voff16, &raw[128 * wave]);
       pred = *reinterpret_cast<const u32 *> (g - 4);
     }
     else {
-      issue_chunk (seq, n_bytes, g0w + 16l * lane, &raw[128 * wave]);
-      issue_chunk (seq, n_bytes, g0w + 1024l + 16l * lane, &raw[128 * wave + 64]);
-      pred = stream_byte (seq, n_bytes, g0w - 1) << 24;
+      issue_chunk (seq, n_bytes, (long) g0w + 16l * lane, &raw[128 * wave]);
+      issue_chunk (seq, n_bytes, (long) g0w + 1024l + 16l * lane, &raw[128 * wave + 64]);
+      pred = stream_byte (seq, n_bytes, (long) g0w - 1) << 24;
     }
   };
-  if (tile < n_ftiles && taken (tile)) prefetch (tile);
+  if (tile < nt_all && fast_any) prefetch (tile);
 
   STAMP_DECL;
-  while (tile < n_ftiles) {
+  while (tile < nt_all) {
     STAMP (0);
-    if (tid == 0 && tile + FK_GROUP == grp_end) T.grp[gpar ^ 1u] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP);
-    const u32 slot = it % 3u, slot2 = (it + 2u) % 3u;
-    if (tid == 0) { T.ncand[slot2] = 0; T.bad[slot2] = 0; }
-    const bool inside = taken (tile);
+    const u32 slot = it & 3u;
+    if (wave == 0) {
+      if (tile + FK_GROUP == grp_end) { if (lane == 0) T.grp[gpar ^ 1u] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP); }
+      if (lane == 0) { T.ncand[(it + 2u) & 3u] = 0; T.bad[(it + 2u) & 3u] = 0; }      // (zeroed two tiles ahead)
+    }
     u32 S32 = 0, L32 = 0;
     const u32 pred_now = pred;
-    if (inside) {
+    if (fast_any) {
       // ---- phase 1: 32 bytes per lane -> codes, run starts, letters -------------------------------------------
       asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has landed in raw
       STAMP (1);
       const uint4 va = raw[2 * tid], vb = raw[2 * tid + 1];
       u32 x[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-      if (!interior (tile)) {                           // (uniform; the stream's first and last tiles) chunks that are not wholly inside the stream: byte by byte
+      if (!(tile >= 1 && tile <= t_hi)) {               // (uniform; the stream's first and last tiles) chunks that are not wholly inside the stream: byte by byte
         const long p0 = tile * (long) FK_OWN - FK_HL + 32l * tid;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -1409,16 +1470,17 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     }
     STAMP (2);
     // the tile after this one
-    const long nt = (tile + 1 < grp_end) ? tile + 1 : (long) T.grp[gpar ^ 1u];
-    if (inside) asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw has been read: it may be refilled
-    if (nt < n_ftiles && taken (nt)) prefetch (nt);
+    int nt = tile + 1;
+    if (nt >= grp_end) nt = __builtin_amdgcn_readfirstlane ((int) T.grp[gpar ^ 1u]);
+    if (fast_any) asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw has been read: it may be refilled
+    if (nt < nt_all && fast_any) prefetch (nt);
     STAMP (3);
 
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 1          // experiment builds only (tools/exp_fast_phases.sh)
     if (S32 == 0x12345u && L32 == 0x54321u) T.bad[3] = 1u;
     S32 = 0;
 #endif
-    if (inside) {
+    if (fast_any) {
       // ---- phase 2: candidate tract starts among this lane's 32 positions ----------------------------------
       // (the next lane's run starts come by DPP; the wave's last lane assumes none, i.e. that runs go on: phase 3
       // checks the length anyway)
@@ -1428,16 +1490,19 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       const u32 n = (u32) __popc (cand);
       const u32 incl = wave_inclusive_scan (n);
       const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, 63);
-      u32 wbase = 0;
-      if (lane == 63 && total) wbase = atomicAdd (&T.ncand[slot], total);
-      wbase = (u32) __builtin_amdgcn_readlane ((int) wbase, 63);
-      u32 at = wbase + incl - n;
+      u32 wraw;
+      lds_add_issue (ncand_addr + 4u * slot, total, wraw);
       const u32 p0 = (u32) (FK_UNIT * tid);
-      while (cand) {
-        const u32 b = (u32) __ffs ((int) cand) - 1u;
-        cand &= cand - 1u;
-        T.cand[min (at, (u32) FK_MAXCAND)] = (unsigned short) (p0 | b);     // (entry FK_MAXCAND: spare slot for a tile that will be given up)
-        at++;
+      const u32 wbase = lds_collect (wraw);
+      // (a wave whose candidates would not all fit leaves its list alone: the tile is given up below)
+      if (wbase + total <= (u32) FK_MAXCAND) {
+        u32 at = wbase + incl - n;
+        while (cand) {
+          const u32 b = (u32) __ffs ((int) cand) - 1u;
+          cand &= cand - 1u;
+          T.cand[at] = (unsigned short) (p0 | b);
+          at++;
+        }
       }
     }
     STAMP (4);
@@ -1448,9 +1513,9 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #if defined(FK_EXP_STOP) && FK_EXP_STOP <= 2
     const u32 ncand_all = (T.ncand[slot] == 0x7FFFFFFFu) ? 1u : 0u;
 #else
-    const u32 ncand_all = T.ncand[slot];
+    const u32 ncand_all = (u32) __builtin_amdgcn_readfirstlane ((int) T.ncand[slot]);
 #endif
-    const bool give_up = !inside || T.bad[slot] != 0u || ncand_all > (u32) FK_MAXCAND;
+    const bool give_up = !fast_any || __builtin_amdgcn_readfirstlane ((int) T.bad[slot]) != 0 || ncand_all > (u32) FK_MAXCAND;
     if (give_up) {
       if (tid == 0) slow_list[atomicAdd (&ctr->lc[par].n_slow, 1u)] = (u32) tile;
     }
@@ -1469,53 +1534,69 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       }
       else
       for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
+        // Straight-line path for a tract whose k + length + k positions fit one 32-bit window (everything else is
+        // `general`), without branches: lanes past the list's end work on its last entry again and are masked out at the
+        // end.  The windows depend on s alone, so all their LDS reads are in flight together: run starts from s + 1,
+        // letters from s - k, and 64 bits of codes from s - k (left flank, tract, right flank).
+#if !(defined(FK_EXP_STOP) && FK_EXP_STOP == 3)
+        sink.reserve1 ((u32) min (ncand - cb0, FK_BLOCK));    // (may partition: before anything of this round is in registers)
+#endif
+        if (cb0 + 64 * wave >= ncand) continue;            // (whole waves without a candidate in this round)
         const int ci = cb0 + tid;
-        bool ok = false, general = false;
-        u32 lo = 0, hi = 0, s = 0;
-        if (ci < ncand) {
-          // Straight-line path for a tract whose k + length + k positions fit one 32-bit window (everything else is
-          // `general`).  The windows depend on s alone, so all their LDS reads are in flight together: run starts from
-          // s + 1, letters from s - k, and 64 bits of codes from s - k (left flank, tract, right flank).
-          s = T.cand[ci];
-          const u32 q = s + 1u, u = s - vk;
-          const u32 *ps = &T.st[q >> 5], *pl = &T.lt[u >> 5], *pc = &T.code[u >> 4];
-          const u32 s0 = ps[0], s1 = ps[1], l0 = pl[0], l1 = pl[1], w0 = pc[0], w1 = pc[1], w2 = pc[2];
-          // run end: first run start after s (bit 31 set: "none in 32 positions" reads as a run of 32, which is general)
-          const u32 len = (u32) __builtin_ctz (__builtin_amdgcn_alignbit (s1, s0, q) | 0x80000000u) + 1u;
-          const u32 need = len + vk2;                      // k letters, the tract, k letters
-          general = need > 32u;
-          const u32 notl = ~__builtin_amdgcn_alignbit (l1, l0, u);
-          ok = !general && ((notl << (v32 - need)) == 0u) && (len >= vmp);
-          const u32 sh = u + u;
-          const u32 clo = __builtin_amdgcn_alignbit (w1, w0, sh), chi = __builtin_amdgcn_alignbit (w2, w1, sh);
-          const u32 l = clo & vkm;
-          const u32 cb = (clo >> vk2) & 3u;                // the tract's base
-          const u32 r = (u32) ((((u64) chi << 32) | clo) >> (vk2 + len + len)) & vkm;
-          // canonical orientation (reference: src/hopo_counter.c:233-246): T / G tracts store the reverse complement
-          const u32 rcl = revcomp_v32 (l, M55, vrs), rcr = revcomp_v32 (r, M55, vrs);
-          const bool rev = cb >= 2u;
-          const u32 c0 = rev ? rcr : l, c1 = rev ? rcl : r;
-          // base << 2 | flag << 3 by table look-up on cb: A (0, fwd) 8, C (1, fwd) 12, G (-> C, rev) 20, T (-> A, rev) 16
-          const u32 fld = __builtin_amdgcn_perm (0u, 0x10140C08u, cb | 0x0C0C0C00u);
-          lo = c1 | (len << 24);
-          hi = c0 | (fld << 24);
-        }
+        const bool valid = ci < ncand;
+        const u32 s = T.cand[min (ci, ncand - 1)];
+        const u32 q = s + 1u, u = s - vk;
+        const u32 *ps = &T.st[q >> 5], *pl = &T.lt[u >> 5], *pc = &T.code[u >> 4];
+        u32 s0 = ps[0], s1 = ps[1], l0 = pl[0], l1 = pl[1], w0 = pc[0], w1 = pc[1], w2 = pc[2];
+        // (pinned: left alone the compiler waits for the run starts before it asks for the codes, and reads the letters
+        // only inside a branch it makes up -- three LDS round trips in a row instead of one)
+        asm volatile ("" : "+v"(s0), "+v"(s1), "+v"(l0), "+v"(l1), "+v"(w0), "+v"(w1), "+v"(w2));
+        // run end: first run start after s (bit 31 set: "none in 32 positions" reads as a run of 32, which is general)
+        const u32 len = (u32) __builtin_ctz (__builtin_amdgcn_alignbit (s1, s0, q) | 0x80000000u) + 1u;
+        const u32 need = len + vk2;                        // k letters, the tract, k letters
+        const bool general = valid && need > 32u;
+        const u32 notl = ~__builtin_amdgcn_alignbit (l1, l0, u);
+        bool ok = valid && (need <= 32u) && ((notl << ((v32 - need) & 31u)) == 0u) && (len >= vmp);
+        u32 glo = 0, ghi = 0;
         if (general) {
           const u64 rec = fast_general_tract (T, seq, n_bytes, g0, (int) s, k, mprime);
-          ok = rec != 0ull; lo = (u32) rec; hi = (u32) (rec >> 32);
+          ok = rec != 0ull; glo = (u32) rec; ghi = (u32) (rec >> 32);
         }
+#if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
+        const u32 at = 0;
+#else
+        // whether the tract is recorded is known: its slot in the staging buffer is asked for now (an LDS atomic per
+        // wave) and the record is worked out while that is on its way
+        const u64 okm = __builtin_amdgcn_ballot_w64 (ok);
+        u32 araw;
+        lds_add_issue (sink.count_addr (), (u32) __builtin_popcountll (okm), araw);
+#endif
+        const u32 sh = u + u;
+        const u32 clo = __builtin_amdgcn_alignbit (w1, w0, sh), chi = __builtin_amdgcn_alignbit (w2, w1, sh);
+        const u32 l = clo & vkm;
+        const u32 cb = (clo >> vk2) & 3u;                  // the tract's base
+        const u32 r = (u32) ((((u64) chi << 32) | clo) >> (vk2 + len + len)) & vkm;
+        // canonical orientation (reference: src/hopo_counter.c:233-246): T / G tracts store the reverse complement
+        const u32 rcl = revcomp_v32 (l, M55, vrs), rcr = revcomp_v32 (r, M55, vrs);
+        const bool rev = cb >= 2u;
+        const u32 c0 = rev ? rcr : l, c1 = rev ? rcl : r;
+        // base << 2 | flag << 3 by table look-up on cb: A (0, fwd) 8, C (1, fwd) 12, G (-> C, rev) 20, T (-> A, rev) 16
+        const u32 fld = __builtin_amdgcn_perm (0u, 0x10140C08u, cb | 0x0C0C0C00u);
+        const u32 lo = general ? glo : (c1 | (len << 24));
+        const u32 hi = general ? ghi : (c0 | (fld << 24));
         STAMP (6);
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
-        if (ok) asm volatile ("" :: "v"(lo), "v"(hi));
+        if (ok) asm volatile ("" :: "v"(lo), "v"(hi), "v"(at));
 #else
-        if constexpr (W == 1) sink.put1 (ok, lo, hi, (u32) min (ncand - cb0, FK_BLOCK));
+        const u32 at = lds_collect (araw) + (u32) __builtin_amdgcn_mbcnt_hi ((u32) (okm >> 32), __builtin_amdgcn_mbcnt_lo ((u32) okm, 0u));
+        if (ok) sink.store1 (at, lo, hi);
 #endif
         STAMP (7);
       }
     }
     lds_barrier ();
     STAMP (8);
-    if (tile + 1 >= grp_end) { gpar ^= 1u; grp_end = nt + FK_GROUP; }
+    if (nt >= grp_end) { gpar ^= 1u; grp_end = nt + FK_GROUP; }
     tile = nt;
     it++;
   }
