@@ -1373,7 +1373,15 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   // byte offsets fit an int.  Tiles 1 .. t_hi have their whole window (and the 16 bytes in front) inside the stream.
   const int nt_all = (int) n_ftiles, nb = (int) n_bytes;
   const int t_hi = (nb >= FK_WIN - FK_HL) ? (nb - (FK_WIN - FK_HL)) / FK_OWN : 0;
-  const bool fast_any = !all_slow;
+  if (all_slow) {                                       // (tests: every tile goes to the generic kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      for (int t = 0; t < nt_all; t++) slow_list[t] = (u32) t;
+      ctr->lc[par].n_slow = (u32) nt_all; ctr->lc[par].work = (u32) nt_all;
+      ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0;
+    }
+    sink.finish ();
+    return;
+  }
   const u32 ncand_addr = (u32) (size_t) (lptr_t) &T.ncand[0];
 
   if (wave == 0) {
@@ -1396,7 +1404,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   u32 pred = 0;
   auto prefetch = [&] (int t) {
     const int g0w = t * FK_OWN - FK_HL + 2048 * wave;   // stream position of the wave's first byte
-    if (t >= 1 && t <= t_hi) {
+    if ((u32) (t - 1) < (u32) t_hi) {
       const uint8_t *g = seq + g0w;
       lds_dma32 (g, voff16, &raw[128 * wave]);
       pred = *reinterpret_cast<const u32 *> (g - 4);
@@ -1407,7 +1415,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       pred = stream_byte (seq, n_bytes, (long) g0w - 1) << 24;
     }
   };
-  if (tile < nt_all && fast_any) prefetch (tile);
+  if (tile < nt_all) prefetch (tile);
 
   STAMP_DECL;
   while (tile < nt_all) {
@@ -1415,17 +1423,17 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     const u32 slot = it & 3u;
     if (wave == 0) {
       if (tile + FK_GROUP == grp_end) { if (lane == 0) T.grp[gpar ^ 1u] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP); }
-      if (lane == 0) { T.ncand[(it + 2u) & 3u] = 0; T.bad[(it + 2u) & 3u] = 0; }      // (zeroed two tiles ahead)
+      if (lane == 0) T.ncand[(it + 2u) & 3u] = 0;        // (zeroed two tiles ahead)
     }
     u32 S32 = 0, L32 = 0;
     const u32 pred_now = pred;
-    if (fast_any) {
+    {
       // ---- phase 1: 32 bytes per lane -> codes, run starts, letters -------------------------------------------
       asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has landed in raw
       STAMP (1);
       const uint4 va = raw[2 * tid], vb = raw[2 * tid + 1];
       u32 x[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-      if (!(tile >= 1 && tile <= t_hi)) {               // (uniform; the stream's first and last tiles) chunks that are not wholly inside the stream: byte by byte
+      if (!((u32) (tile - 1) < (u32) t_hi)) {            // (uniform; the stream's first and last tiles) chunks that are not wholly inside the stream: byte by byte
         const long p0 = tile * (long) FK_OWN - FK_HL + 32l * tid;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -1466,27 +1474,35 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       *reinterpret_cast<uint2 *> (&T.code[2 * tid]) = make_uint2 (code_lo, code_hi);
       T.st[tid] = S32;
       T.lt[tid] = L32;
-      if (bad) T.bad[slot] = 1u;
+      if (bad) T.ncand[slot] = 0x40000000u;              // (more candidates than any tile has: given up below; later atomic adds keep it so)
     }
     STAMP (2);
     // the tile after this one
     int nt = tile + 1;
     if (nt >= grp_end) nt = __builtin_amdgcn_readfirstlane ((int) T.grp[gpar ^ 1u]);
-    if (fast_any) asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw has been read: it may be refilled
-    if (nt < nt_all && fast_any) prefetch (nt);
+    asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw has been read: it may be refilled
+    if (nt < nt_all) prefetch (nt);
     STAMP (3);
 
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 1          // experiment builds only (tools/exp_fast_phases.sh)
     if (S32 == 0x12345u && L32 == 0x54321u) T.bad[3] = 1u;
     S32 = 0;
 #endif
-    if (fast_any) {
+    {
       // ---- phase 2: candidate tract starts among this lane's 32 positions ----------------------------------
       // (the next lane's run starts come by DPP; the wave's last lane assumes none, i.e. that runs go on: phase 3
       // checks the length anyway)
       const u32 nx = (u32) __builtin_amdgcn_update_dpp (0, (int) S32, 0x130, 0xF, 0xF, false);   // wave_shl:1
       u32 cand = S32 & L32 & own;
-      for (int j = 1; j < mprime; j++) cand &= ~__builtin_amdgcn_alignbit (nx, S32, (u32) j);
+      // no run start at the next mprime - 1 positions (the usual minimum lengths without a loop: its scalar bookkeeping
+      // costs more than the vector work)
+      {
+        const u32 a1 = __builtin_amdgcn_alignbit (nx, S32, 1u), a2 = __builtin_amdgcn_alignbit (nx, S32, 2u);
+        if (mprime == 3) cand = cand & ~(a1 | a2);
+        else if (mprime == 2) cand = cand & ~a1;
+        else if (mprime == 4) cand = cand & ~(a1 | a2 | __builtin_amdgcn_alignbit (nx, S32, 3u));
+        else for (int j = 1; j < mprime; j++) cand &= ~__builtin_amdgcn_alignbit (nx, S32, (u32) j);
+      }
       const u32 n = (u32) __popc (cand);
       const u32 incl = wave_inclusive_scan (n);
       const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, 63);
@@ -1515,14 +1531,14 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #else
     const u32 ncand_all = (u32) __builtin_amdgcn_readfirstlane ((int) T.ncand[slot]);
 #endif
-    const bool give_up = !fast_any || __builtin_amdgcn_readfirstlane ((int) T.bad[slot]) != 0 || ncand_all > (u32) FK_MAXCAND;
+    const bool give_up = ncand_all > (u32) FK_MAXCAND;    // (or a byte outside the alphabet)
     if (give_up) {
       if (tid == 0) slow_list[atomicAdd (&ctr->lc[par].n_slow, 1u)] = (u32) tile;
     }
     else {
       const int ncand = (int) ncand_all;
-      const long g0 = tile * (long) FK_OWN - FK_HL;
-      if constexpr (W != 1) {                           // k > 12: two windows per plane (the flanks do not fit one with the tract)
+      if constexpr (W != 1) {
+        const long g0 = tile * (long) FK_OWN - FK_HL;                           // k > 12: two windows per plane (the flanks do not fit one with the tract)
         for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
           const int ci = cb0 + tid;
           bool have = false;
@@ -1559,7 +1575,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         bool ok = valid && (need <= 32u) && ((notl << ((v32 - need) & 31u)) == 0u) && (len >= vmp);
         u32 glo = 0, ghi = 0;
         if (general) {
-          const u64 rec = fast_general_tract (T, seq, n_bytes, g0, (int) s, k, mprime);
+          const u64 rec = fast_general_tract (T, seq, n_bytes, tile * (long) FK_OWN - FK_HL, (int) s, k, mprime);
           ok = rec != 0ull; glo = (u32) rec; ghi = (u32) (rec >> 32);
         }
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
