@@ -924,15 +924,15 @@ struct StageLds
   // (BIG: scan_fast_kernel, two workgroups per CU: twice the records per pass, runs twice as long)
   static constexpr int WORDS = ((W == 1) ? TJ_STAGE_WORDS : 2688) * (BIG ? 2 : 1);
   static constexpr int S = WORDS / WS;                   // records
-  u64 rec[WORDS];
-  u64 gbase[TJ_P];                                      // pool index of the first record of the bucket's run
-  u64 gbase2[TJ_P];                                     // pool index of the part of the run that lies in the next chunk
-  u32 hist[TJ_P];
-  u32 offs[TJ_P];                                       // start of the bucket's run in the sorted staging buffer
-  u32 split[TJ_P];                                      // records of the run before the chunk boundary
+  u64 rec[WORDS + (BIG ? 64 : 0)];                      // (BIG: slots S + lane take the writes of lanes without a record)
+  u64 gbase[TJ_P];                                      // pool index of the first record of the bucket's run (BIG: byte address of sorted slot 0's place, see partition_big)
+  u64 gbase2[TJ_P];                                     // pool index of the part of the run that lies in the next chunk (BIG: likewise)
+  u32 hist[TJ_P + (BIG ? 64 : 0)];                      // (BIG: entries TJ_P + lane are for the lanes without a record)
+  u32 offs[TJ_P + (BIG ? 64 : 0)];                       // start of the bucket's run in the sorted staging buffer
+  u32 split[TJ_P];                                      // records of the run before the chunk boundary (BIG: first sorted slot past it)
   u32 wsum[TJ_P / 64];
   u32 n;
-  unsigned char bin[S];
+  unsigned char bin[S + (BIG ? 64 : 0)];
 };
 
 template <int W, int BLOCK, bool BIG = false>
@@ -1004,8 +1004,133 @@ struct StageSink
     L.bin[at] = (unsigned char) bucket_of_rec1 (lo, hi);
   }
 
+  // The partition of the fast kernel's one-word records (BIG), written without per-record branches: every lane always
+  // loads, ranks, permutes and stores; a lane whose slot holds no record works on bucket TJ_P / staging slot S, which exist
+  // for that purpose, and only its store to the pool is masked.  (A branch per record costs three scalar instructions and
+  // an exec round trip; scalar instructions are as dear as vector ones here.)
+  __device__ __forceinline__ void partition_big ()
+  {
+    static_assert (!BIG || (W == 1 && BLOCK == 2 * TJ_P), "one-word records, two threads per bucket");
+    constexpr int H = 4;                                // records per thread whose LDS loads are in flight together
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);
+    lds_barrier ();                                     // every append so far is in LDS
+#if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 1            // experiment builds only: records dropped
+    if (tid == 0) L.n = 0;
+    lds_barrier ();
+    return;
+#endif
+    PSTAMP (9);
+    const u32 n = (u32) __builtin_amdgcn_readfirstlane ((int) L.n);
+    if (tid < TJ_P + 64) L.hist[tid] = 0;
+    lds_barrier ();
+    if (tid == 0) L.n = 0;                              // (everybody has read it; the next appends come after the last barrier below)
+    // Rounds r with r * BLOCK >= n hold no record at all and are skipped by a scalar branch; in the one partial round the
+    // lanes past n use bucket TJ_P + lane and staging slot S + lane (64 spare entries each: no pile-up on one address).
+    u64 w[R];
+    u32 rk[R], bb[R];
+#pragma unroll
+    for (int r = 0; r < R; r++)                         // my records ...
+      if ((u32) r * BLOCK < n) {
+        const u32 i = (u32) tid + (u32) r * BLOCK;
+        bb[r] = L.bin[i];
+        w[r] = L.rec[i];
+      }
+#pragma unroll
+    for (int r = 0; r < R; r++)                         // ... and their rank inside their bucket
+      if ((u32) r * BLOCK < n) {
+        const u32 i = (u32) tid + (u32) r * BLOCK;
+        bb[r] = (i < n) ? bb[r] : (u32) (TJ_P + lane);
+        rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
+      }
+    lds_barrier ();
+    PSTAMP (10);
+    u32 cnt = 0, incl = 0, p0 = 0;
+    if (wave < TJ_P / 64) {                             // exclusive prefix of the bucket counts (waves 0..3)
+      cnt = L.hist[tid];
+      incl = wave_inclusive_scan (cnt);
+      if (lane == 63) L.wsum[wave] = incl;
+    }
+    else if (wave == TJ_P / 64) L.offs[tid] = (u32) S + (u32) lane;   // (the spare entries: rank 0 lands on staging slot S + lane)
+    lds_barrier ();
+    if (wave < TJ_P / 64) {
+      u32 wbase = 0;
+      for (int v = 0; v < wave; v++) wbase += L.wsum[v];
+      L.offs[tid] = wbase + incl - cnt;
+      // reserve the bucket's run: the global atomic's round trip runs under the LDS permutation below (its result is
+      // first looked at after that)
+      if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
+    }
+    lds_barrier ();
+    PSTAMP (11);
+    {
+      u32 dst[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) if ((u32) r * BLOCK < n) dst[r] = L.offs[bb[r]];
+#pragma unroll
+      for (int r = 0; r < R; r++)                       // in-place permutation into bucket order (records are in registers)
+        if ((u32) r * BLOCK < n) {
+          const u32 d = dst[r] + ((bb[r] < (u32) TJ_P) ? rk[r] : 0u);
+          L.rec[d] = w[r];
+          L.bin[d] = (unsigned char) bb[r];
+        }
+    }
+    PSTAMP (12);
+    if (wave < TJ_P / 64) {                             // where the reserved run lives: byte addresses of "sorted slot 0" for both parts
+      u64 a1 = 0, a2 = 0;
+      u32 thr = 0;
+      if (cnt) {
+        const u32 ch = (u32) TJ_CH0 << B.ch_shift;
+        const u32 off = L.offs[tid];
+        bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
+        const u32 j0 = chunk_of_pos (B, p0), j1 = chunk_of_pos (B, p0 + cnt - 1);
+        if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (B, (u32) tid, j0, true, ctr); }
+        if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (B.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch))) - 8ull * off;
+        thr = off + cnt;
+        if (j1 != j0) {                                 // the run crosses into the next chunk
+          thr = off + (j1 * ch - p0);
+          cur_j = j1; cur_chunk = bucket_chunk_id (B, (u32) tid, j1, true, ctr);
+          if (cur_chunk != TJ_NOCHUNK) a2 = (u64) (size_t) (B.pool + (u64) cur_chunk * ch) - 8ull * thr;
+        }
+      }
+      L.split[tid] = thr; L.gbase[tid] = a1; L.gbase2[tid] = a2;
+    }
+    PSTAMP (13);
+    lds_barrier ();
+    PSTAMP (14);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += H)
+      if ((u32) r0 * BLOCK < n) {
+        u32 cb[H], cthr[H];
+        u64 ca1[H], ca2[H], cw[H];
+#pragma unroll
+        for (int h = 0; h < H; h++) cb[h] = L.bin[(u32) tid + (u32) (r0 + h) * BLOCK];
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+          const u32 i = (u32) tid + (u32) (r0 + h) * BLOCK;
+          const u32 b = cb[h] & (u32) (TJ_P - 1);       // (slots past n hold stale bytes: any bucket will do, the store is masked)
+          cthr[h] = L.split[b]; ca1[h] = L.gbase[b]; ca2[h] = L.gbase2[b];
+          cw[h] = L.rec[i];
+        }
+#pragma unroll
+        for (int h = 0; h < H; h++) {                   // sorted slot i -> its place in the bucket's run (coalesced per run)
+          const u32 i = (u32) tid + (u32) (r0 + h) * BLOCK;
+          const u64 a = (i < cthr[h]) ? ca1[h] : ca2[h];
+#if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 3
+          if (a == 0x123456789ull)
+#else
+          if (i < n && a != 0ull)
+#endif
+            *reinterpret_cast<u64 *> (a + 8ull * i) = cw[h];
+        }
+      }
+    lds_barrier ();                                     // the staging buffer is free again
+    PSTAMP (15);
+  }
+
   __device__ __forceinline__ void partition ()
   {
+    if constexpr (BIG) { partition_big (); return; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef TJ_EXP_PRIO
     __builtin_amdgcn_s_setprio (TJ_EXP_PRIO);
