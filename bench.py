@@ -367,7 +367,7 @@ def main():
     dominant = "scan" if scan_avg >= fin_avg else "finalise"
     # HBM bytes per launch from the PMC passes of the same command (tools/pmc_traffic.py -> profiles/; rocprofv3 cannot
     # run inside the timed process), only when they were taken on this workload
-    scan_kernel = "scan_fast_kernel<1>" if k <= 12 else ("scan_bins_kernel<2>" if k <= 28 else "scan_bins_kernel<4>")
+    scan_kernel = "scan_fast_kernel<%d>" % (1 if k <= 12 else (2 if k <= 28 else 4))
     traffic, traffic_src = None, None
     prof = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
     try:

@@ -921,18 +921,21 @@ struct StageLds
   // three-word formats get 21 KB instead of 16: fewer, fuller partition passes (their fixed cost is per pass), still three
   // workgroups per CU
   static constexpr int WS = (W == 4) ? 3 : W;
-  // (BIG: scan_fast_kernel, two workgroups per CU: twice the records per pass, runs twice as long)
-  static constexpr int WORDS = ((W == 1) ? TJ_STAGE_WORDS : 2688) * (BIG ? 2 : 1);
+  // BIG = the fast kernel's sink (scan_fast_kernel, two workgroups per CU): one-word records are staged 4096 at a time
+  // (twice the records per pass, runs twice as long), and every array has 64 spare entries so that partition_big can do
+  // without per-record branches
+  static constexpr int WORDS = (W == 1) ? TJ_STAGE_WORDS * (BIG ? 2 : 1) : 2688;
   static constexpr int S = WORDS / WS;                   // records
-  u64 rec[WORDS + (BIG ? 64 : 0)];                      // (BIG: slots S + lane take the writes of lanes without a record)
+  static constexpr int SPARE = BIG ? 64 : 0;
+  u64 rec[WORDS + SPARE * WS];                          // (BIG: slots S + lane take the writes of lanes without a record)
   u64 gbase[TJ_P];                                      // pool index of the first record of the bucket's run (BIG: byte address of sorted slot 0's place, see partition_big)
   u64 gbase2[TJ_P];                                     // pool index of the part of the run that lies in the next chunk (BIG: likewise)
-  u32 hist[TJ_P + (BIG ? 64 : 0)];                      // (BIG: entries TJ_P + lane are for the lanes without a record)
-  u32 offs[TJ_P + (BIG ? 64 : 0)];                       // start of the bucket's run in the sorted staging buffer
+  u32 hist[TJ_P + SPARE];                               // (BIG: entries TJ_P + lane are for the lanes without a record)
+  u32 offs[TJ_P + SPARE];                               // start of the bucket's run in the sorted staging buffer
   u32 split[TJ_P];                                      // records of the run before the chunk boundary (BIG: first sorted slot past it)
   u32 wsum[TJ_P / 64];
   u32 n;
-  unsigned char bin[S + (BIG ? 64 : 0)];
+  unsigned char bin[S + SPARE];
 };
 
 template <int W, int BLOCK, bool BIG = false>
@@ -947,9 +950,6 @@ struct StageSink
   u32 bound;                                            // upper bound of the records staged (workgroup-uniform)
   u32 cur_j, cur_chunk;                                 // owner thread (tid < TJ_P): the chunk its bucket is being written to
   STAMP_MEMBER
-#if defined(TJ_EXP_SINK)
-  u32 exp_prev = 0;
-#endif
 
   __device__ __forceinline__ void start ()
   {
@@ -1003,15 +1003,24 @@ struct StageSink
     L.rec[at * WS] = ((u64) hi << 32) | lo;
     L.bin[at] = (unsigned char) bucket_of_rec1 (lo, hi);
   }
+  __device__ __forceinline__ void store_fields (u32 at, u64 c0, u64 c1, u32 base, u32 len10, u32 flag)
+  {
+    u64 w[W];
+    pack_raw<W> (c0, c1, base, len10, flag, k, w);
+#pragma unroll
+    for (int j = 0; j < WS; j++) L.rec[at * WS + j] = w[j];
+    L.bin[at] = (unsigned char) (W == 1 ? bucket_of_rec1 ((u32) w[0], (u32) (w[0] >> 32)) : bucket_of_key (c0, c1, base, len10));
+  }
 
-  // The partition of the fast kernel's one-word records (BIG), written without per-record branches: every lane always
-  // loads, ranks, permutes and stores; a lane whose slot holds no record works on bucket TJ_P / staging slot S, which exist
-  // for that purpose, and only its store to the pool is masked.  (A branch per record costs three scalar instructions and
-  // an exec round trip; scalar instructions are as dear as vector ones here.)
+  // The partition of the fast kernel's sink (BIG), written without per-record branches: a lane whose slot holds no
+  // record works on spare bucket TJ_P + lane and spare staging slot S + lane, which exist for that purpose, and only its
+  // store to the pool is masked; rounds r with r * BLOCK >= n hold no record at all and are skipped by a scalar branch.
+  // (A branch per record costs three scalar instructions and an exec round trip, and scalar instructions are as dear as
+  // vector ones on this chip.)
   __device__ __forceinline__ void partition_big ()
   {
-    static_assert (!BIG || (W == 1 && BLOCK == 2 * TJ_P), "one-word records, two threads per bucket");
-    constexpr int H = 4;                                // records per thread whose LDS loads are in flight together
+    static_assert (!BIG || BLOCK == 2 * TJ_P, "two threads per bucket");
+    constexpr int H = (R < 4) ? R : 4;                  // records per thread whose LDS loads are in flight together
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);
     lds_barrier ();                                     // every append so far is in LDS
@@ -1025,16 +1034,15 @@ struct StageSink
     if (tid < TJ_P + 64) L.hist[tid] = 0;
     lds_barrier ();
     if (tid == 0) L.n = 0;                              // (everybody has read it; the next appends come after the last barrier below)
-    // Rounds r with r * BLOCK >= n hold no record at all and are skipped by a scalar branch; in the one partial round the
-    // lanes past n use bucket TJ_P + lane and staging slot S + lane (64 spare entries each: no pile-up on one address).
-    u64 w[R];
+    u64 w[R][WS];
     u32 rk[R], bb[R];
 #pragma unroll
     for (int r = 0; r < R; r++)                         // my records ...
       if ((u32) r * BLOCK < n) {
         const u32 i = (u32) tid + (u32) r * BLOCK;
         bb[r] = L.bin[i];
-        w[r] = L.rec[i];
+#pragma unroll
+        for (int j = 0; j < WS; j++) w[r][j] = L.rec[i * WS + j];
       }
 #pragma unroll
     for (int r = 0; r < R; r++)                         // ... and their rank inside their bucket
@@ -1071,7 +1079,8 @@ struct StageSink
       for (int r = 0; r < R; r++)                       // in-place permutation into bucket order (records are in registers)
         if ((u32) r * BLOCK < n) {
           const u32 d = dst[r] + ((bb[r] < (u32) TJ_P) ? rk[r] : 0u);
-          L.rec[d] = w[r];
+#pragma unroll
+          for (int j = 0; j < WS; j++) L.rec[d * WS + j] = w[r][j];
           L.bin[d] = (unsigned char) bb[r];
         }
     }
@@ -1085,12 +1094,12 @@ struct StageSink
         bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
         const u32 j0 = chunk_of_pos (B, p0), j1 = chunk_of_pos (B, p0 + cnt - 1);
         if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (B, (u32) tid, j0, true, ctr); }
-        if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (B.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch))) - 8ull * off;
+        if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (B.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch)) * W) - (8ull * W) * off;
         thr = off + cnt;
         if (j1 != j0) {                                 // the run crosses into the next chunk
           thr = off + (j1 * ch - p0);
           cur_j = j1; cur_chunk = bucket_chunk_id (B, (u32) tid, j1, true, ctr);
-          if (cur_chunk != TJ_NOCHUNK) a2 = (u64) (size_t) (B.pool + (u64) cur_chunk * ch) - 8ull * thr;
+          if (cur_chunk != TJ_NOCHUNK) a2 = (u64) (size_t) (B.pool + ((u64) cur_chunk * ch) * W) - (8ull * W) * thr;
         }
       }
       L.split[tid] = thr; L.gbase[tid] = a1; L.gbase2[tid] = a2;
@@ -1102,18 +1111,19 @@ struct StageSink
     for (int r0 = 0; r0 < R; r0 += H)
       if ((u32) r0 * BLOCK < n) {
         u32 cb[H], cthr[H];
-        u64 ca1[H], ca2[H], cw[H];
+        u64 ca1[H], ca2[H], cw[H][WS];
 #pragma unroll
-        for (int h = 0; h < H; h++) cb[h] = L.bin[(u32) tid + (u32) (r0 + h) * BLOCK];
+        for (int h = 0; h < H; h++) if (r0 + h < R) cb[h] = L.bin[(u32) tid + (u32) (r0 + h) * BLOCK];
 #pragma unroll
-        for (int h = 0; h < H; h++) {
+        for (int h = 0; h < H; h++) if (r0 + h < R) {
           const u32 i = (u32) tid + (u32) (r0 + h) * BLOCK;
           const u32 b = cb[h] & (u32) (TJ_P - 1);       // (slots past n hold stale bytes: any bucket will do, the store is masked)
           cthr[h] = L.split[b]; ca1[h] = L.gbase[b]; ca2[h] = L.gbase2[b];
-          cw[h] = L.rec[i];
+#pragma unroll
+          for (int j = 0; j < WS; j++) cw[h][j] = L.rec[i * WS + j];
         }
 #pragma unroll
-        for (int h = 0; h < H; h++) {                   // sorted slot i -> its place in the bucket's run (coalesced per run)
+        for (int h = 0; h < H; h++) if (r0 + h < R) {   // sorted slot i -> its place in the bucket's run (coalesced per run)
           const u32 i = (u32) tid + (u32) (r0 + h) * BLOCK;
           const u64 a = (i < cthr[h]) ? ca1[h] : ca2[h];
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 3
@@ -1121,7 +1131,12 @@ struct StageSink
 #else
           if (i < n && a != 0ull)
 #endif
-            *reinterpret_cast<u64 *> (a + 8ull * i) = cw[h];
+          {
+            u64 *q = reinterpret_cast<u64 *> (a + (8ull * W) * i);
+#pragma unroll
+            for (int j = 0; j < WS; j++) q[j] = cw[h][j];
+            if (WS < W) q[W - 1] = 0;
+          }
         }
       }
     lds_barrier ();                                     // the staging buffer is free again
@@ -1131,56 +1146,27 @@ struct StageSink
   __device__ __forceinline__ void partition ()
   {
     if constexpr (BIG) { partition_big (); return; }
+    // (scan_bins_kernel, 80 registers: one record at a time)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef TJ_EXP_PRIO
-    __builtin_amdgcn_s_setprio (TJ_EXP_PRIO);
-#endif
     lds_barrier ();                                     // every append so far is in LDS
-#if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 1            // experiment builds only: records dropped
-    if (tid == 0) L.n = 0;
-    lds_barrier ();
-    return;
-#endif
-    PSTAMP (9);
     const u32 n = L.n;
     if (tid < TJ_P) L.hist[tid] = 0;
     lds_barrier ();
     if (tid == 0) L.n = 0;                              // (everybody has read it; the next appends come after the last barrier below)
-    // (every stage below first issues all its LDS loads, whatever the record count -- slot tid + r * BLOCK always exists --
-    // and only then uses them: with the loads inside the `i < n` branches each of a thread's R records paid its own
-    // LDS round trips, one after the other)
     u64 w[R][WS];
     u32 rk[R], bb[R];
-    if constexpr (BIG) {
 #pragma unroll
-      for (int r = 0; r < R; r++) {                     // my records ...
-        const u32 i = (u32) tid + (u32) r * BLOCK;
+    for (int r = 0; r < R; r++) {                       // my records and their rank inside their bucket
+      const u32 i = (u32) tid + (u32) r * BLOCK;
+      bb[r] = TJ_EMPTY;
+      if (i < n) {
         bb[r] = L.bin[i];
 #pragma unroll
         for (int j = 0; j < WS; j++) w[r][j] = L.rec[i * WS + j];
-      }
-#pragma unroll
-      for (int r = 0; r < R; r++) {                     // ... and their rank inside their bucket
-        const u32 i = (u32) tid + (u32) r * BLOCK;
-        if (i < n) rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
-        else bb[r] = TJ_EMPTY;
-      }
-    }
-    else {                                              // (scan_bins_kernel, 80 registers: one record at a time)
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        const u32 i = (u32) tid + (u32) r * BLOCK;
-        bb[r] = TJ_EMPTY;
-        if (i < n) {
-          bb[r] = L.bin[i];
-#pragma unroll
-          for (int j = 0; j < WS; j++) w[r][j] = L.rec[i * WS + j];
-          rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
-        }
+        rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
       }
     }
     lds_barrier ();
-    PSTAMP (10);
     u32 cnt = 0, incl = 0;
     if (tid < TJ_P) {                                   // exclusive prefix of the bucket counts (waves 0..3)
       cnt = L.hist[tid];
@@ -1195,37 +1181,17 @@ struct StageSink
       L.offs[tid] = wbase + incl - cnt;
       // reserve the bucket's run: the global atomic's round trip runs under the LDS permutation below (its result is
       // first looked at after that)
-#if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 2             // timing experiment: the reservation of the pass before (no wait for this one)
-      p0 = exp_prev; if (cnt) exp_prev = atomicAdd (&B.cursors[tid], cnt);
-#else
       if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
-#endif
     }
     lds_barrier ();
-    PSTAMP (11);
-    if constexpr (BIG) {
-      u32 dst[R];
 #pragma unroll
-      for (int r = 0; r < R; r++) dst[r] = L.offs[bb[r] & (TJ_P - 1)] + rk[r];
+    for (int r = 0; r < R; r++)                         // in-place permutation into bucket order (records are in registers)
+      if (bb[r] != TJ_EMPTY) {
+        const u32 d = L.offs[bb[r]] + rk[r];
 #pragma unroll
-      for (int r = 0; r < R; r++)                        // in-place permutation into bucket order (records are in registers)
-        if (bb[r] != TJ_EMPTY) {
-#pragma unroll
-          for (int j = 0; j < WS; j++) L.rec[dst[r] * WS + j] = w[r][j];
-          L.bin[dst[r]] = (unsigned char) bb[r];
-        }
-    }
-    else {
-#pragma unroll
-      for (int r = 0; r < R; r++)
-        if (bb[r] != TJ_EMPTY) {
-          const u32 d = L.offs[bb[r]] + rk[r];
-#pragma unroll
-          for (int j = 0; j < WS; j++) L.rec[d * WS + j] = w[r][j];
-          L.bin[d] = (unsigned char) bb[r];
-        }
-    }
-    PSTAMP (12);
+        for (int j = 0; j < WS; j++) L.rec[d * WS + j] = w[r][j];
+        L.bin[d] = (unsigned char) bb[r];
+      }
     if (tid < TJ_P && cnt) {                            // where the reserved run lives
       const u32 ch = (u32) TJ_CH0 << B.ch_shift;
       bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
@@ -1241,61 +1207,22 @@ struct StageSink
       }
       L.split[tid] = sp; L.gbase2[tid] = g2;
     }
-    PSTAMP (13);
     lds_barrier ();
-    PSTAMP (14);
-    if constexpr (BIG) {
-      u32 cb[R], co[R], csp[R];
-      u64 cg1[R], cg2[R], cw[R][WS];
 #pragma unroll
-      for (int r = 0; r < R; r++) cb[r] = L.bin[(u32) tid + (u32) r * BLOCK];
+    for (int r = 0; r < R; r++) {                       // sorted slot i -> its place in the bucket's run (coalesced per run)
+      const u32 i = (u32) tid + (u32) r * BLOCK;
+      if (i < n) {
+        const u32 b = L.bin[i], o = i - L.offs[b], sp = L.split[b];
+        const u64 g = (o < sp) ? L.gbase[b] : L.gbase2[b];
+        if (g != ~0ull) {
+          u64 *q = B.pool + (g + (o < sp ? o : o - sp)) * W;
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        const u32 i = (u32) tid + (u32) r * BLOCK;
-        co[r] = i - L.offs[cb[r]]; csp[r] = L.split[cb[r]]; cg1[r] = L.gbase[cb[r]]; cg2[r] = L.gbase2[cb[r]];
-#pragma unroll
-        for (int j = 0; j < WS; j++) cw[r][j] = L.rec[i * WS + j];
-      }
-#pragma unroll
-      for (int r = 0; r < R; r++) {                     // sorted slot i -> its place in the bucket's run (coalesced per run)
-        const u32 i = (u32) tid + (u32) r * BLOCK;
-        if (i < n) {
-          const u32 o = co[r], sp = csp[r];
-          const u64 g = (o < sp) ? cg1[r] : cg2[r];
-#if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 3
-          if (g == 0x123456789ull) {
-#else
-          if (g != ~0ull) {
-#endif
-            u64 *q = B.pool + (g + (o < sp ? o : o - sp)) * W;
-#pragma unroll
-            for (int j = 0; j < WS; j++) q[j] = cw[r][j];
-            if (WS < W) q[W - 1] = 0;
-          }
-        }
-      }
-    }
-    else {
-#pragma unroll
-      for (int r = 0; r < R; r++) {                     // sorted slot i -> its place in the bucket's run (coalesced per run)
-        const u32 i = (u32) tid + (u32) r * BLOCK;
-        if (i < n) {
-          const u32 b = L.bin[i], o = i - L.offs[b], sp = L.split[b];
-          const u64 g = (o < sp) ? L.gbase[b] : L.gbase2[b];
-          if (g != ~0ull) {
-            u64 *q = B.pool + (g + (o < sp ? o : o - sp)) * W;
-#pragma unroll
-            for (int j = 0; j < WS; j++) q[j] = L.rec[i * WS + j];
-            if (WS < W) q[W - 1] = 0;
-          }
+          for (int j = 0; j < WS; j++) q[j] = L.rec[i * WS + j];
+          if (WS < W) q[W - 1] = 0;
         }
       }
     }
     lds_barrier ();                                     // the staging buffer is free again
-#ifdef TJ_EXP_PRIO
-    __builtin_amdgcn_s_setprio (0);
-#endif
-    PSTAMP (15);
   }
 
   __device__ __forceinline__ void finish () { partition (); }
@@ -1468,11 +1395,8 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 {
   __shared__ FastLds T;
   __shared__ uint4 raw[FK_WIN / 16];
-#ifndef FK_BIG
-#define FK_BIG (W == 1)
-#endif
-  __shared__ StageLds<W, FK_BIG> SL;
-  StageSink<W, FK_BLOCK, FK_BIG> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
+  __shared__ StageLds<W, true> SL;
+  StageSink<W, FK_BLOCK, true> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
   sink.start ();
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1647,7 +1571,9 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       }
     }
     STAMP (4);
+#if !(defined(FK_EXP_NOBAR) && (FK_EXP_NOBAR & 2))
     lds_barrier ();
+#endif
     STAMP (5);
 
     // ---- phase 3: one lane per candidate ----------------------------------------------------------------------
@@ -1662,15 +1588,21 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     }
     else {
       const int ncand = (int) ncand_all;
-      if constexpr (W != 1) {
-        const long g0 = tile * (long) FK_OWN - FK_HL;                           // k > 12: two windows per plane (the flanks do not fit one with the tract)
+      if constexpr (W != 1) {                           // k > 12: two windows per plane (the flanks do not fit one with the tract)
+        const long g0 = tile * (long) FK_OWN - FK_HL;
         for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
+          sink.reserve1 ((u32) min (ncand - cb0, FK_BLOCK));   // (may partition)
+          if (cb0 + 64 * wave >= ncand) continue;          // (whole waves without a candidate in this round)
           const int ci = cb0 + tid;
           bool have = false;
           u64 c0 = 0, c1 = 0;
           u32 base = 0, len10 = 0, flag = 0;
           if (ci < ncand) have = fast_tract<false> (T, seq, n_bytes, g0, (int) T.cand[ci], k, mprime, c0, c1, base, len10, flag);
-          sink.put (have, c0, c1, base, len10, flag, 0ull, (u32) min (ncand - cb0, FK_BLOCK));
+          const u64 okm = __builtin_amdgcn_ballot_w64 (have);
+          u32 araw;
+          lds_add_issue (sink.count_addr (), (u32) __builtin_popcountll (okm), araw);
+          const u32 at = lds_collect (araw) + (u32) __builtin_amdgcn_mbcnt_hi ((u32) (okm >> 32), __builtin_amdgcn_mbcnt_lo ((u32) okm, 0u));
+          if (have) sink.store_fields (at, c0, c1, base, len10, flag);
         }
       }
       else
@@ -1735,7 +1667,9 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         STAMP (7);
       }
     }
+#if !(defined(FK_EXP_NOBAR) && (FK_EXP_NOBAR & 1))     // (timing experiment only: results are wrong without it)
     lds_barrier ();
+#endif
     STAMP (8);
     if (nt >= grp_end) { gpar ^= 1u; grp_end = nt + FK_GROUP; }
     tile = nt;
