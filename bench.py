@@ -52,17 +52,42 @@ def self_launch(args):
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
+    import tempfile
+    import time as _time
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # a rank that dies must not leave the others waiting in a rendezvous or a collective: the first non-zero exit ends
+    # the job (exactly the processes started here, by their handles)
+    rcs = [None] * len(procs)
+    failed = False
+    while any(rc is None for rc in rcs) and not failed:
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+                if rcs[i] not in (None, 0):
+                    failed = True
+        if not failed:
+            _time.sleep(0.05)
+    if failed:
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                pr.terminate()
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                try:
+                    rcs[i] = pr.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    rcs[i] = pr.wait()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return max(abs(rc) for rc in rcs) if not failed else max(1, max(abs(rc) for rc in rcs if rc not in (None,)))
 
 
 def rehearse(args):
@@ -71,6 +96,8 @@ def rehearse(args):
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("TATAJUBA_BENCH_REHEARSE_FAIL_RANK") == str(rank):     # (tests: a rank that dies before the rendezvous)
+        raise SystemExit(3)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dist.barrier()

@@ -103,3 +103,14 @@ def test_bench_launches_its_own_ranks():
     assert "configs[3]" in d["config"]["workload"]                          # the label follows the arguments
     r = subprocess.run([sys.executable, bench, "--rehearse", "--kmer", "13"], env=env, stdout=subprocess.PIPE, timeout=300)
     assert "custom workload" in json.loads(r.stdout.decode().splitlines()[-1])["config"]["workload"]
+
+
+def test_bench_launcher_ends_the_job_when_a_rank_dies():
+    # rank 1 exits before the rendezvous; rank 0 would wait for it for minutes: the launcher has to end it and fail
+    import subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TATAJUBA_BENCH_REHEARSE_FAIL_RANK="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    t = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse"], env=env, capture_output=True, timeout=120)
+    assert p.returncode != 0 and time.time() - t < 90
