@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_HERE, os.environ.get("TJ_DIAG_LIB", "libtatajuba_amd.so"))     # (TJ_DIAG_LIB: an experimental build, tools/ only)
-_SOURCES = ["hopo_device.hip", "hopo_host.c", "fastq_reader.c", "fastq_reader.h", "feeder.c", "feeder.h", "synth.c", "exports.map", "Makefile",
+_SOURCES = ["hopo_device.hip", "hopo_host.c", "fastq_reader.c", "fastq_reader.h", "feeder.c", "feeder.h", "tj_inflate.c", "tj_inflate.h", "synth.c", "exports.map", "Makefile",
             os.path.join("..", "..", "include", "tatajuba_amd.h"), os.path.join("..", "..", "include", "tatajuba_hopo.h")]
 
 

@@ -37,6 +37,7 @@
 #include <stdio.h>
 #include <time.h>
 #include <zlib.h>
+#include "tj_inflate.h"
 
 static double tjf_now (void) { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec; }
 
@@ -384,8 +385,15 @@ typedef struct
   int bgzf;             /* the members at zpos are BGZF blocks (until one is not) */
   int ended;            /* nothing more will come (end of input, trailing garbage, damaged stream) */
   int damaged;
-  z_stream strm;        /* the one-thread inflater (gzip wrapper), live across views */
+  int crc_failed;       /* a member inflated by tj_inflate.c did not match its own CRC-32 / size: results cannot be trusted */
+  int use_zlib;         /* TATAJUBA_AMD_FEEDER_INFLATE=zlib: zlib's inflate() instead of tj_inflate.c (tests, comparison) */
+  z_stream strm;        /* (use_zlib) the one-thread inflater, gzip wrapper, live across views */
+  tji_state *inf;       /* the one-thread inflater of the member at hand, live across views */
   int strm_open;
+  unsigned long crc;    /* of the member's output so far */
+  unsigned long long isize;
+  unsigned char hist[32768];    /* the member's last output: goes in front of the next view's payload (LZ77 window) */
+  size_t hist_len;
   int n_threads;
   tjz_block *blk;
   size_t blk_cap;
@@ -416,24 +424,73 @@ tjz_inflate_blocks (void *arg)
 {
   tjz_job *j = (tjz_job *) arg;
   z_stream zs;
+  tji_state *ti = j->src->use_zlib ? NULL : (tji_state *) malloc (sizeof (tji_state));
+  int zs_open = 0;
   size_t b;
-  memset (&zs, 0, sizeof zs);
   j->bad_at_set = 0;
-  if (inflateInit2 (&zs, -15) != Z_OK) { j->bad_at_set = 1; j->bad_at = j->first; return NULL; }
   for (b = j->first; b < j->last; b++) {
     const tjz_block *k = &j->src->blk[b];
-    int rc;
+    int ok = 0;
     if (k->isize == 0) continue;                        /* (the empty block bgzip ends a file with) */
-    inflateReset (&zs);
-    zs.next_in = (Bytef *) (j->src->z + k->data_off); zs.avail_in = (uInt) k->data_len;
-    zs.next_out = j->out + k->out_off; zs.avail_out = k->isize;
-    rc = inflate (&zs, Z_FINISH);
-    if (rc != Z_STREAM_END || zs.avail_out != 0 || (unsigned) crc32 (crc32 (0L, Z_NULL, 0), j->out + k->out_off, k->isize) != k->crc) {
-      j->bad_at_set = 1; j->bad_at = b; break;
+    if (ti) {
+      size_t ip = 0, op = 0;
+      tji_init (ti);
+      ok = tji_inflate (ti, j->src->z + k->data_off, k->data_len, &ip, j->out + k->out_off, k->isize, &op, 0) == TJI_DONE && op == k->isize
+           && tji_crc32 (0u, j->out + k->out_off, k->isize) == k->crc;
+    }
+    if (!ok) {                                          /* zlib's word on it (always, with use_zlib) */
+      int rc;
+      if (!zs_open) { memset (&zs, 0, sizeof zs); if (inflateInit2 (&zs, -15) != Z_OK) { j->bad_at_set = 1; j->bad_at = b; break; } zs_open = 1; }
+      else inflateReset (&zs);
+      zs.next_in = (Bytef *) (j->src->z + k->data_off); zs.avail_in = (uInt) k->data_len;
+      zs.next_out = j->out + k->out_off; zs.avail_out = k->isize;
+      rc = inflate (&zs, Z_FINISH);
+      if (rc != Z_STREAM_END || zs.avail_out != 0 || (unsigned) crc32 (crc32 (0L, Z_NULL, 0), j->out + k->out_off, k->isize) != k->crc) {
+        j->bad_at_set = 1; j->bad_at = b; break;
+      }
     }
   }
-  inflateEnd (&zs);
+  if (zs_open) inflateEnd (&zs);
+  free (ti);
   return NULL;
+}
+
+/* CRC-32 of a stretch of output by several threads (zlib's crc32 does 1 GB/s, the inflater should not wait for it) */
+typedef struct { const unsigned char *p; size_t n; unsigned long crc; } tjz_crc_job;
+static void *tjz_crc_run (void *arg) { tjz_crc_job *c = (tjz_crc_job *) arg; c->crc = tji_crc32 (0u, c->p, c->n); return NULL; }
+static unsigned long
+tjz_crc_extend (unsigned long crc, const unsigned char *p, size_t n, int n_threads)
+{
+  tjz_crc_job job[TJF_MAX_THREADS];
+  pthread_t th[TJF_MAX_THREADS];
+  int started[TJF_MAX_THREADS], t, nt = n_threads;
+  if (nt > TJF_MAX_THREADS) nt = TJF_MAX_THREADS;
+  if (n < (4u << 20) || nt < 2) { tjz_crc_job one = {p, n, 0}; tjz_crc_run (&one); return crc32_combine (crc, one.crc, (z_off_t) n); }
+  for (t = 0; t < nt; t++) {
+    const size_t a = n * (size_t) t / (size_t) nt, b = n * (size_t) (t + 1) / (size_t) nt;
+    job[t].p = p + a; job[t].n = b - a; started[t] = 0;
+    if (t) { if (pthread_create (&th[t], NULL, tjz_crc_run, &job[t]) == 0) started[t] = 1; else tjz_crc_run (&job[t]); }
+  }
+  tjz_crc_run (&job[0]);
+  for (t = 1; t < nt; t++) if (started[t]) pthread_join (th[t], NULL);
+  for (t = 0; t < nt; t++) crc = crc32_combine (crc, job[t].crc, (z_off_t) job[t].n);
+  return crc;
+}
+
+/* length of the gzip member header at p (RFC 1952), 0 if it is none that zlib would take (or cut short) */
+static size_t
+tjz_member_header (const unsigned char *p, size_t avail)
+{
+  size_t x = 10;
+  unsigned flg;
+  if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) return 0;
+  flg = p[3];
+  if (flg & 0xe0u) return 0;                            /* reserved flag bits */
+  if (flg & 4u) { if (x + 2 > avail) return 0; x += 2 + ((size_t) p[x] | ((size_t) p[x + 1] << 8)); }
+  if (flg & 8u) { while (x < avail && p[x]) x++; x++; }
+  if (flg & 16u) { while (x < avail && p[x]) x++; x++; }
+  if (flg & 2u) x += 2;
+  return x < avail ? x : 0;
 }
 
 /* the next inflated bytes of the file into out[0, cap) (cap >= 64 KiB); 0 only when nothing is left */
@@ -486,6 +543,49 @@ tjz_fill (tjz_source *s, unsigned char *out, size_t cap)
     }
     /* any other gzip stream: one inflater, members one after the other (what gzread does: zlib's gzread.c gz_look /
      * gz_decomp -- another member if the next two bytes are 1f 8b, anything else after a member is ignored) */
+    if (!s->use_zlib) {
+      size_t ip, op = 0;
+      int rc;
+      if (!s->strm_open) {
+        const size_t h = tjz_member_header (s->z + s->zpos, s->zn - s->zpos);
+        if (!h) { s->ended = 1; s->damaged = 1; break; }
+        if (!s->inf) s->inf = (tji_state *) malloc (sizeof (tji_state));
+        if (!s->inf) { s->ended = 1; s->damaged = 1; break; }
+        tji_init (s->inf);
+        s->zpos += h; s->strm_open = 1; s->crc = crc32 (0L, Z_NULL, 0); s->isize = 0; s->hist_len = 0;
+      }
+      else if (got == 0 && s->hist_len) memcpy (out - s->hist_len, s->hist, s->hist_len);   /* (the room is there: feeder views keep >= 64 KiB in front) */
+      ip = s->zpos;
+      rc = tji_inflate (s->inf, s->z, s->zn, &ip, out + got, cap - got, &op, got == 0 ? s->hist_len : 0);
+      s->zpos = ip;
+      s->crc = tjz_crc_extend (s->crc, out + got, op, s->n_threads);
+      s->isize += op;
+      if (rc == TJI_DONE) {
+        s->strm_open = 0; s->hist_len = 0;
+        if (s->zn - s->zpos < 8) { s->ended = 1; s->damaged = 1; }
+        else {
+          const unsigned char *t = s->z + s->zpos;
+          const unsigned long c = (unsigned long) t[0] | ((unsigned long) t[1] << 8) | ((unsigned long) t[2] << 16) | ((unsigned long) t[3] << 24);
+          const unsigned long n = (unsigned long) t[4] | ((unsigned long) t[5] << 8) | ((unsigned long) t[6] << 16) | ((unsigned long) t[7] << 24);
+          s->zpos += 8;
+          if (c != (s->crc & 0xffffffffUL) || n != (unsigned long) (s->isize & 0xffffffffULL)) { s->ended = 1; s->crc_failed = 1; }
+          else if (s->zn - s->zpos < 2 || s->z[s->zpos] != 0x1f || s->z[s->zpos + 1] != 0x8b) s->ended = 1;
+          else { size_t d; s->bgzf = tjz_bgzf_block (s->z + s->zpos, s->zn - s->zpos, &d) != 0; }
+        }
+      }
+      else if (rc == TJI_OUTPUT_FULL) {                 /* the view is full: keep the window for the next one */
+        if (op >= sizeof s->hist) { memcpy (s->hist, out + got + op - sizeof s->hist, sizeof s->hist); s->hist_len = sizeof s->hist; }
+        else {
+          const size_t keep = s->hist_len < sizeof s->hist - op ? s->hist_len : sizeof s->hist - op;
+          memmove (s->hist, s->hist + s->hist_len - keep, keep);
+          memcpy (s->hist + keep, out + got, op);
+          s->hist_len = keep + op;
+        }
+      }
+      else { s->ended = 1; s->damaged = 1; }            /* truncated or not DEFLATE */
+      got += op;
+      continue;
+    }
     if (!s->strm_open) {
       memset (&s->strm, 0, sizeof s->strm);
       if (inflateInit2 (&s->strm, 15 + 16) != Z_OK) { s->ended = 1; s->damaged = 1; break; }
@@ -540,6 +640,7 @@ tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const t
   if (reserve > payload) reserve = payload;
   { size_t d; src.bgzf = tjz_bgzf_block (src.z, src.zn, &d) != 0; }
   src.n_threads = n_threads < 1 ? 1 : (n_threads > TJF_MAX_THREADS ? TJF_MAX_THREADS : n_threads);
+  { const char *e = getenv ("TATAJUBA_AMD_FEEDER_INFLATE"); src.use_zlib = e && !strcmp (e, "zlib"); }
   tjf_stat_windows = 0; tjf_stat_fallback = 0; tjf_stat_bgzf = 0;
   if (tjf_state_init (&s, sink, n_threads, window_bytes + reserve)) { tjf_state_free (&s); munmap ((void *) src.z, src.zn); return -2; }
   for (cur = 0; cur < 2; cur++) {
@@ -583,12 +684,14 @@ tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const t
   if (fill_running) { if (fill_threaded) pthread_join (fth, NULL); }
   if (sink->sync) (void) sink->sync (sink->ctx);
   if (src.damaged) fprintf (stderr, "tatajuba_amd: '%s' is truncated or damaged; reading stops where its gzip stream breaks\n", path);
-  if (src.strm_open) inflateEnd (&src.strm);
+  if (src.strm_open && src.use_zlib) inflateEnd (&src.strm);
+  free (src.inf);
   free (src.blk);
   free (view[0]); free (view[1]);
   tjf_state_free (&s);
   munmap ((void *) src.z, src.zn);
   tjf_trace (&s, path, tjf_stat_bgzf ? "bgzf" : "gzip", t0, t_inflate);
   total = s.total_reads;
+  if (src.crc_failed && total >= 0) total = -4;         /* (what was handed to the sink cannot be trusted) */
   return total;
 }

@@ -24,7 +24,9 @@ int tjf_is_plain_file (const char *path);
 long tjf_parse_file (const char *path, int n_threads, size_t window_bytes, const tjf_sink *sink);
 
 /* The same for a gzip file (first two bytes 1f 8b): a producer thread inflates one view of window_bytes ahead of the
- * parse -- BGZF members by n_threads threads side by side, any other gzip stream by one.  Same return values. */
+ * parse -- BGZF members by n_threads threads side by side, any other gzip stream by one (tj_inflate.c; zlib's inflate
+ * with TATAJUBA_AMD_FEEDER_INFLATE=zlib).  Same return values, and -4 if a member did not match its own CRC-32 / size
+ * after it had been handed on (a damaged file, or a decoder fault: either way the counter's content is void). */
 long tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const tjf_sink *sink);
 long tjf_last_bgzf_blocks (void);                           /* BGZF members the last call inflated side by side */
 

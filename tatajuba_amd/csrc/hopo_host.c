@@ -11,6 +11,7 @@
 #include <unistd.h>
 #include "fastq_reader.h"
 #include "feeder.h"
+#include "tj_inflate.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -225,6 +226,7 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
       got = plain ? tjf_parse_file (filename, threads, (size_t) TJ_FEEDER_WINDOW, &sk)
                   : tjf_parse_gz_file (filename, threads, (size_t) TJ_FEEDER_GZ_WINDOW, &sk);
       if (got == -2 || got == -3) tj_fatal ("%s", got == -2 ? "out of pinned host memory for the feeder" : tjamd_last_error ());
+      if (got == -4) tj_fatal ("'%s': a gzip member does not match its own CRC-32 / size (damaged file); set TATAJUBA_AMD_FEEDER_INFLATE=zlib to read it the reference's way", filename);
       if (got >= 0) {
         n = tjamd_raw_count (g.dev);
         if (n < 0) tj_fatal ("%s", tjamd_last_error ());
@@ -316,6 +318,40 @@ tjamd_read_file_stream_mt (const char *path, unsigned char *out, long capacity, 
 /* diagnostic (not in the public header): windows the feeder accepted in its last call, and whether it fell back */
 long tjamd_debug_feeder_stats (long *fell_back) { long w = 0; tjf_last_stats (&w, fell_back); return w; }
 long tjamd_debug_feeder_bgzf_blocks (void) { return tjf_last_bgzf_blocks (); }
+
+unsigned tjamd_debug_crc32 (const unsigned char *p, long n) { return tji_crc32 (0u, p, (size_t) n); }
+
+/* diagnostic (tests): the feeder's DEFLATE decoder on a raw stream, its output produced `chunk` bytes at a time in a
+ * buffer that is reused -- the last 32 KiB moved in front of it each time, as the feeder does between two windows.
+ * Returns the inflated size (-1: error, -2: truncated, -3: out too small); *in_used = bytes of `in` consumed. */
+long
+tjamd_debug_inflate (const unsigned char *in, long in_len, unsigned char *out, long out_cap, long chunk, long *in_used)
+{
+  tji_state *st = (tji_state *) malloc (sizeof (tji_state));
+  unsigned char *buf = (unsigned char *) malloc (32768 + (size_t) chunk);
+  size_t in_pos = 0, hist = 0;
+  long total = 0, rc;
+  tji_init (st);
+  for (;;) {
+    size_t out_pos = 0;
+    const int r = tji_inflate (st, in, (size_t) in_len, &in_pos, buf + 32768, (size_t) chunk, &out_pos, hist);
+    if (total + (long) out_pos > out_cap) { rc = -3; break; }
+    memcpy (out + total, buf + 32768, out_pos);
+    total += (long) out_pos;
+    if (r == TJI_DONE) { rc = total; break; }
+    if (r == TJI_ERROR) { rc = -1; break; }
+    if (r == TJI_MORE_INPUT) { rc = -2; break; }
+    /* output full: the last 32 KiB of everything written so far go in front of the buffer */
+    {
+      const size_t have = hist + out_pos, keep = have < 32768 ? have : 32768;
+      memmove (buf + 32768 - keep, buf + 32768 + out_pos - keep, keep);
+      hist = keep;
+    }
+  }
+  if (in_used) *in_used = (long) in_pos;
+  free (buf); free (st);
+  return rc;
+}
 
 /* ---- one sequence, synchronously (reference: src/hopo_counter.c:219-258) ------------------------------------------ */
 

@@ -348,6 +348,75 @@ def test_gzip_feeder_truncated_file_stops_where_the_stream_breaks(tmp_path):
         assert whole.startswith(got.tobytes().decode()[: -102] if n else "")   # ... and it is a prefix of the file's reads
 
 
+def test_inflate_decoder_matches_zlib_on_random_streams():
+    # the feeder's own DEFLATE decoder (csrc/tj_inflate.c) against zlib: every block type, every level and strategy,
+    # flush points, output taken in pieces of odd sizes (the decoder stops and resumes anywhere), and the exact input length
+    import ctypes as C, zlib
+    L = tj.lib()
+    L.tjamd_debug_inflate.restype = C.c_long
+    L.tjamd_debug_inflate.argtypes = [C.c_char_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.POINTER(C.c_long)]
+    L.tjamd_debug_crc32.restype = C.c_uint
+    L.tjamd_debug_crc32.argtypes = [C.c_char_p, C.c_long]
+    rng = random.Random(5)
+    nrng = np.random.default_rng(5)
+
+    def make(kind, n):
+        if kind == "random":
+            return nrng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        if kind == "dna":
+            return bytes(nrng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+        if kind == "fastq":
+            return _adversarial_file(nrng, n // 250 + 1).encode()[:n]
+        if kind == "runs":
+            return b"".join(bytes([rng.randrange(256)]) * rng.choice([1, 2, 3, 7, 8, 9, 100, 258, 259, 5000]) for _ in range(max(1, n // 200)))[:n]
+        return (b"the quick brown fox jumps over the lazy dog " * (n // 44 + 1))[:n]
+
+    for it in range(150):
+        kind = rng.choice(["random", "dna", "fastq", "runs", "text"])
+        data = make(kind, rng.choice([0, 1, 2, 5, 100, 1000, 40000, 70000, 300000]))
+        co = zlib.compressobj(rng.randrange(10), zlib.DEFLATED, -15, 9,
+                              rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
+        parts, step = [], rng.choice([len(data) + 1, 1000, 65536])
+        for i in range(0, len(data), step):
+            parts.append(co.compress(data[i:i + step]))
+            if rng.random() < 0.3:
+                parts.append(co.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])))
+        comp = b"".join(parts) + co.flush()
+        full = comp + b"0123456789abcdef"                   # (a gzip member goes on after the stream)
+        out = np.empty(len(data) + 64, np.uint8)
+        for chunk in (rng.choice([1, 7, 333, 4096, 70000]), 1 << 22):
+            used = C.c_long(-1)
+            got = L.tjamd_debug_inflate(full, len(full), out.ctypes.data, out.size, chunk, C.byref(used))
+            assert got == len(data) and out[:got].tobytes() == data and used.value == len(comp), (it, kind, len(data), chunk, got)
+        assert L.tjamd_debug_crc32(data, len(data)) == zlib.crc32(data)
+    for it in range(200):                                   # anything else is refused, not run off with
+        junk = nrng.integers(0, 256, rng.choice([1, 10, 100, 5000]), dtype=np.uint8).tobytes()
+        out = np.empty(1 << 18, np.uint8)
+        L.tjamd_debug_inflate(junk, len(junk), out.ctypes.data, out.size, 4096, None)
+    comp = zlib.compress(make("fastq", 200000), 6)[2:-4]
+    for cut in (1, 10, 1000, len(comp) // 2, len(comp) - 1):    # a truncated stream says so
+        out = np.empty(300000, np.uint8)
+        assert L.tjamd_debug_inflate(comp[:cut], cut, out.ctypes.data, out.size, 1 << 20, None) in (-1, -2)
+
+
+def test_gzip_feeder_refuses_a_member_that_fails_its_checksum(tmp_path, monkeypatch):
+    import gzip
+    from tatajuba_amd.capi import read_file_stream_mt
+    txt = (CASES["fastq4"] * 3000).encode()
+    blob = bytearray(gzip.compress(txt, 6))
+    blob[-6] ^= 0x40                                        # the stored CRC-32
+    p = str(tmp_path / "badcrc.fq.gz")
+    open(p, "wb").write(bytes(blob))
+    with pytest.raises(Exception):
+        read_file_stream_mt(p, 4, 65536)
+    good = str(tmp_path / "good.fq.gz")
+    open(good, "wb").write(gzip.compress(txt, 6))
+    for mode in ("", "zlib"):                               # both inflaters, same bytes
+        monkeypatch.setenv("TATAJUBA_AMD_FEEDER_INFLATE", mode)
+        got, n = read_file_stream_mt(good, 4, 65536)
+        assert n == 6000
+
+
 def test_fixture_file_stream(golden_dir, known_answers):
     s, n = tj.read_file_stream(os.path.join(golden_dir, "err1750956.fastq.gz"))
     f = known_answers["file"]
