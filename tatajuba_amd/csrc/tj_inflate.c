@@ -10,6 +10,7 @@
  */
 #include "tj_inflate.h"
 #include <string.h>
+#include <pthread.h>
 
 #define LIT_TABLE_BITS   11
 #define DIST_TABLE_BITS  8
@@ -383,7 +384,7 @@ save:
 /* ---- CRC-32 (the gzip polynomial, reflected 0xEDB88320), slicing by 16: zlib 1.2.11's crc32() does 1 GB/s, which next to
  * this inflater is a third of the time per byte.  Same values as zlib's crc32 (tests compare them). ---- */
 static unsigned tji_crc_tab[16][256];
-static int tji_crc_ready = 0;
+static pthread_once_t tji_crc_once = PTHREAD_ONCE_INIT;
 
 static void
 tji_crc_init (void)
@@ -395,13 +396,12 @@ tji_crc_init (void)
     tji_crc_tab[0][i] = c;
   }
   for (i = 0; i < 256; i++) for (j = 1; j < 16; j++) tji_crc_tab[j][i] = (tji_crc_tab[j - 1][i] >> 8) ^ tji_crc_tab[0][tji_crc_tab[j - 1][i] & 0xffu];
-  __atomic_store_n (&tji_crc_ready, 1, __ATOMIC_RELEASE);
 }
 
 unsigned
 tji_crc32 (unsigned crc, const unsigned char *p, size_t n)
 {
-  if (!__atomic_load_n (&tji_crc_ready, __ATOMIC_ACQUIRE)) tji_crc_init ();    /* (idempotent: threads may race to fill the same values) */
+  pthread_once (&tji_crc_once, tji_crc_init);
   crc = ~crc;
   while (n && ((size_t) p & 7u)) { crc = (crc >> 8) ^ tji_crc_tab[0][(crc ^ *p++) & 0xffu]; n--; }
   while (n >= 16) {
