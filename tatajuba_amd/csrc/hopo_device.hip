@@ -1776,6 +1776,7 @@ struct Agg1Lds
   u32 cnt[2 * AG1_S];                   // per slot: records seen on the forward / on the reverse strand
   u32 chunk[AG_NCH];                    // the bucket's chunk ids
   u32 n_claimed, n_ovf, total;
+  u32 next_batch;                       // batches of 64 * AG1_R records are handed to the waves as they come for one
   u32 wsum[AG_BLOCK / 64];
 };
 
@@ -1798,16 +1799,16 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
   while (n > 0) {
     ASTAMP (0);
     for (int i = tid; i < AG1_S; i += AG_BLOCK) { L.key[i] = 0; L.cnt[2 * i] = 0; L.cnt[2 * i + 1] = 0; }
-    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.next_batch = 0; }
     __syncthreads ();
 
     // AG1_R records per lane are in flight while the previous AG1_R are inserted: with one 8-byte load per lane the
     // kernel sat at latency x (8 KB per CU in flight) = 1.4 TB/s whatever the table did.
     u64 wn[AG1_R];
     u32 vn = 0;
-    // A round is AG_BLOCK * AG1_R consecutive records of the bucket: less than a chunk, so it lies in at most two
-    // chunks and everything about them is workgroup-uniform (chunk ids come from LDS: no global look-up whose wait
-    // would also wait for the records in flight).
+    // A batch is 64 * AG1_R consecutive records of the bucket: less than a chunk, so it lies in at most two chunks and
+    // everything about them is wave-uniform (chunk ids come from LDS: no global look-up whose wait would also wait
+    // for the records in flight).
     auto fetch = [&] (u32 b0) {
       vn = 0;
 #pragma unroll
@@ -1819,14 +1820,24 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       const u64 off0 = (u64) c0 * ch - (u64) j0 * ch, off1 = (u64) c1 * ch - (u64) bound;   // record index -> pool index
 #pragma unroll
       for (int r = 0; r < AG1_R; r++) {
-        const u32 idx = b0 + (u32) r * AG_BLOCK + (u32) tid;
+        const u32 idx = b0 + (u32) r * 64u + (u32) lane;
         const bool hi = idx >= bound;
         if (idx < n && (hi ? c1 : c0) != TJ_NOCHUNK) { vn |= 1u << r; wn[r] = src[(hi ? off1 : off0) + idx]; }
       }
     };
-    fetch (0u);
+    // Waves take batches of 64 * AG1_R consecutive records as they become free (one LDS atomic per batch): with a fixed
+    // share per wave the slower waves of a SIMD finished a third of the round after the faster ones had started to wait.
+    auto next_batch = [&] () {
+      u32 b = 0;
+      if (lane == 0) b = atomicAdd (&L.next_batch, 1u);
+      return (u32) __builtin_amdgcn_readfirstlane ((int) b) * (64u * AG1_R);
+    };
+    u32 b_next = next_batch ();
+    fetch (b_next);
     ASTAMP (1);
-    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK * AG1_R) {
+    while (b_next < n) {
+      const u32 b0 = b_next;
+      (void) b0;
       // this round's records have arrived (fetched one round ago).  The registers pass through the asm so that the
       // compiler stops tracking them as pending loads: otherwise it waits for them again at their first use -- after
       // the next round's loads have been issued, i.e. for those as well (vmcnt counts in order).
@@ -1837,7 +1848,8 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
 #pragma unroll
       for (int r = 0; r < AG1_R; r++) w[r] = wn[r];
       const u32 valid = vn;
-      fetch (b0 + AG_BLOCK * AG1_R);
+      b_next = next_batch ();
+      fetch (b_next);
       ASTAMP (3);
       ASTAMP (4);
 #if defined(TJ_EXP_AGG) && TJ_EXP_AGG == 1      // experiment: loads only
