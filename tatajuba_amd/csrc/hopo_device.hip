@@ -423,6 +423,7 @@ __device__ __noinline__ EdgeChunk edge_chunk (const uint8_t *__restrict__ seq, l
 // groups of TJ_TILE_GROUP.  Otherwise: the tiles the fast kernel (scan_fast_kernel) left to this one -- tile t of that
 // kernel owns the tract starts in [t * fown, (t + 1) * fown); each is covered here by NSUB = ceil (fown / TILE) pieces,
 // handed out two at a time (the list is short, or the stream is slow-path material anyway).
+#define TJ_LIST_FOWN 16288               // = FK_OWN (static_assert below): tract starts per listed tile
 struct TileSrc { const u32 *list; long fown; };
 
 template <int BLOCK, int TILE, int CANDDIV, class Sink>
@@ -435,15 +436,24 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
   const u64 km = kmask (k);
   const u64 kbits = (1ull << k) - 1ull;                 // k <= 32
   const bool listed = src.list != nullptr;
-  const u32 nsub = listed ? (u32) ((src.fown + TILE - 1) / TILE) : 1u;
-  // (a group is reserved while its predecessor's first tile is worked on and looked up during the predecessor's last
-  // tile: with at least two tiles per group a workgroup barrier lies between the two)
-  const u32 tgroup = listed ? 2u : (u32) TJ_TILE_GROUP;
+  constexpr u32 nsub_listed = (u32) ((TJ_LIST_FOWN + TILE - 1) / TILE);    // (compile-time: no division per tile)
+  const u32 nsub = listed ? nsub_listed : 1u;
   u32 *const work = listed ? &ctr->lc[par].work_slow : &ctr->lc[par].work;
   if (listed) n_tiles = (long) ctr->lc[par].n_slow * (long) nsub;
-  // first stream byte a work item owns, and how many (multiples of 16)
-  auto own_start = [&] (long w) -> long { return listed ? (long) src.list[(u32) w / nsub] * src.fown + (long) ((u32) w % nsub) * TILE : w * (long) TILE; };
-  auto own_len = [&] (long w) -> int { return listed ? (int) min ((long) TILE, src.fown - (long) ((u32) w % nsub) * TILE) : TILE; };
+  // (a group is reserved while its predecessor's first tile is worked on and looked up during the predecessor's last
+  // tile: with at least two tiles per group a workgroup barrier lies between the two.  A short list is handed out two
+  // pieces at a time, for balance; a long one -- a stream full of N, say -- in groups like the whole stream.)
+  const u32 tgroup = !listed ? (u32) TJ_TILE_GROUP : (n_tiles >= 8l * TJ_TILE_GROUP * (long) gridDim.x) ? (u32) TJ_TILE_GROUP : 2u;
+  // first stream byte a work item owns, and how many (multiples of 16); the list entry of the piece looked at last is
+  // kept (the pieces of one listed tile follow each other)
+  u32 le_idx = 0xFFFFFFFFu; long le_val = 0;
+  auto own_start = [&] (long w) -> long {
+    if (!listed) return w * (long) TILE;
+    const u32 li = (u32) w / nsub_listed;
+    if (li != le_idx) { le_idx = li; le_val = (long) src.list[li] * (long) TJ_LIST_FOWN; }
+    return le_val + (long) ((u32) w % nsub_listed) * TILE;
+  };
+  auto own_len = [&] (long w) -> int { return listed ? (int) min ((long) TILE, (long) TJ_LIST_FOWN - (long) ((u32) w % nsub_listed) * TILE) : TILE; };
 
   // Tiles are handed out dynamically in groups of TJ_TILE_GROUP (one global atomic per group): workgroups differ in
   // how many tracts their tiles hold, and a static split leaves the slow ones running alone at the end.
@@ -1282,6 +1292,7 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
 #define FK_HL       32
 #define FK_HR       64
 #define FK_OWN      (FK_WIN - FK_HL - FK_HR)
+static_assert (FK_OWN == TJ_LIST_FOWN, "scan_tiles' list mode is compiled for the fast kernel's tile size");
 #ifndef FK_MAXCAND
 #define FK_MAXCAND  4096
 #endif
@@ -1297,6 +1308,7 @@ struct FastLds
   u32 ncand[4];                         // per tile, three in rotation (zeroed two tiles ahead)
   u32 bad[4];                           // per tile, likewise: some byte outside ACGT\n
   u32 grp[2];
+  u32 sbuf[32];                         // tiles given up, on their way to the slow list (one global atomic per 32)
 };
 
 // v_bitop3_b32 truth tables: bit (a << 2 | b << 1 | c) of the immediate = f (a, b, c)
@@ -1465,6 +1477,16 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     }
   };
   if (tile < nt_all) prefetch (tile);
+  u32 n_sbuf = 0;                                       // (workgroup-uniform)
+  auto flush_slow = [&] () {
+    if (wave == 0 && n_sbuf) {                          // (thread 0 wrote the entries: same wave, LDS keeps its order)
+      u32 base = 0;
+      if (lane == 0) base = atomicAdd (&ctr->lc[par].n_slow, n_sbuf);
+      base = (u32) __builtin_amdgcn_readfirstlane ((int) base);
+      if ((u32) lane < n_sbuf) slow_list[base + (u32) lane] = T.sbuf[lane];
+    }
+    n_sbuf = 0;
+  };
 
   STAMP_DECL;
   while (tile < nt_all) {
@@ -1584,7 +1606,10 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #endif
     const bool give_up = ncand_all > (u32) FK_MAXCAND;    // (or a byte outside the alphabet)
     if (give_up) {
-      if (tid == 0) slow_list[atomicAdd (&ctr->lc[par].n_slow, 1u)] = (u32) tile;
+      // (listed in batches: one atomic with a return value per tile, on one address for the whole grid, cost 4.6 us each
+      // when every tile of a stream was given up -- more than scanning the tile)
+      if (tid == 0) T.sbuf[n_sbuf] = (u32) tile;
+      if (++n_sbuf == 32u) flush_slow ();
     }
     else {
       const int ncand = (int) ncand_all;
@@ -1676,6 +1701,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     it++;
   }
   STAMP_FLUSH;
+  flush_slow ();
   sink.finish ();
 }
 
