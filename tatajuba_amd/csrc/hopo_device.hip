@@ -1309,6 +1309,8 @@ struct FastLds
   u32 bad[4];                           // per tile, likewise: some byte outside ACGT\n
   u32 grp[2];
   u32 sbuf[32];                         // tiles given up, on their way to the slow list (one global atomic per 32)
+  u32 np[FK_WIN / 32 + 4];              // second chance of a tile (see the kernel): positions that hold an 'N'
+  u32 ncand2;                           // its candidate count
 };
 
 // v_bitop3_b32 truth tables: bit (a << 2 | b << 1 | c) of the immediate = f (a, b, c)
@@ -1331,7 +1333,7 @@ __device__ __forceinline__ u32 revcomp_v32 (u32 x, u32 m55, u32 rs)
 // planes.  Returns false if the tract is not recorded.
 template <bool K32>
 __device__ __forceinline__ bool fast_tract (const FastLds &T, const uint8_t *__restrict__ seq, long n_bytes, long g0, int s, int k, int mprime,
-                                            u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag)
+                                            u64 &c0, u64 &c1, u32 &base, u32 &len10, u32 &flag, bool n_tile = false)
 {
   int e = -1;
   {
@@ -1353,17 +1355,25 @@ __device__ __forceinline__ bool fast_tract (const FastLds &T, const uint8_t *__r
     const u32 kb32 = (k >= 32) ? 0xFFFFFFFFu : (1u << k) - 1u;
     if ((((~bits32 (T.lt, s - k) | ~bits32 (T.lt, e + 1)) & kb32) != 0u) || len < mprime) return false;
     const u32 cb = (T.code[s >> 4] >> (2 * (s & 15))) & 3u;
+    // (a tile with 'N's: an 'N' in a flank has code 0 in the plane, which is what the reference packs for it read forwards;
+    // read backwards it packs 0 as well, not the complement -- its forward code is made 3 before complementing, as
+    // `canonicalise` does for every non-ACGTU byte)
+    u64 nl2 = 0, nr2 = 0;
+    if (n_tile) {
+      const u32 nl = bits32 (T.np, s - k) & kb32, nr = bits32 (T.np, e + 1) & kb32;
+      if (nl | nr) { nl2 = spread_pairs (nl); nr2 = spread_pairs (nr); }
+    }
     if (K32 || k <= 16) {
       const u32 km32 = (k >= 16) ? 0xFFFFFFFFu : (1u << (2 * k)) - 1u;
       const u32 l32 = bits32 (T.code, 2 * (s - k)) & km32, r32 = bits32 (T.code, 2 * (e + 1)) & km32;
       if (cb < 2u) { c0 = l32; c1 = r32; base = cb; flag = 1u; }
-      else { c0 = revcomp_k32 (r32, k); c1 = revcomp_k32 (l32, k); base = 3u - cb; flag = 2u; }
+      else { c0 = revcomp_k32 (r32 | (u32) nr2, k); c1 = revcomp_k32 (l32 | (u32) nl2, k); base = 3u - cb; flag = 2u; }
     }
     else {
       const u64 km = kmask (k);
       const u64 left = bits64 (T.code, 2 * (s - k)) & km, right = bits64 (T.code, 2 * (e + 1)) & km;
       if (cb < 2u) { c0 = left; c1 = right; base = cb; flag = 1u; }
-      else { c0 = revcomp_k (right, k); c1 = revcomp_k (left, k); base = 3u - cb; flag = 2u; }
+      else { c0 = revcomp_k (right | nr2, k); c1 = revcomp_k (left | nl2, k); base = 3u - cb; flag = 2u; }
     }
   }
   else {                                                // the tract runs past the window: walk the stream (rare)
@@ -1383,10 +1393,10 @@ __device__ __forceinline__ bool fast_tract (const FastLds &T, const uint8_t *__r
 // the same, out of line, for the tracts that do not fit the one-word kernel's straight-line path (k + length + k > 32).
 // Returns the packed record, 0 if the tract is not recorded (a record is never 0; by value: a reference parameter of a
 // function that is not inlined would put the caller's variables into scratch memory, in every round).
-__device__ __noinline__ u64 fast_general_tract (const FastLds &T, const uint8_t *__restrict__ seq, long n_bytes, long g0, int s, int k, int mprime)
+__device__ __noinline__ u64 fast_general_tract (const FastLds &T, const uint8_t *__restrict__ seq, long n_bytes, long g0, int s, int k, int mprime, bool n_tile)
 {
   u64 c0, c1; u32 base, len10, flag;
-  if (!fast_tract<true> (T, seq, n_bytes, g0, s, k, mprime, c0, c1, base, len10, flag)) return 0ull;
+  if (!fast_tract<true> (T, seq, n_bytes, g0, s, k, mprime, c0, c1, base, len10, flag, n_tile)) return 0ull;
   return pack_rec1 ((u32) c0, (u32) c1, base, len10, flag);
 }
 
@@ -1450,7 +1460,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       T.grp[0] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP);
       if (blockIdx.x == 0) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; }
     }
-    if (lane < 4) { T.ncand[lane] = 0; T.bad[lane] = 0; T.code[FK_WIN / 16 + lane] = 0; T.st[FK_WIN / 32 + lane] = 0; T.lt[FK_WIN / 32 + lane] = 0; }
+    if (lane < 4) { T.ncand[lane] = 0; T.bad[lane] = 0; T.code[FK_WIN / 16 + lane] = 0; T.st[FK_WIN / 32 + lane] = 0; T.lt[FK_WIN / 32 + lane] = 0; T.np[FK_WIN / 32 + lane] = 0; T.ncand2 = 0; }
   }
   // (phase 3 reads the candidate list with a clamped index instead of a branch: every entry must be a position)
   for (int i = tid; i < FK_MAXCAND + 2; i += FK_BLOCK) T.cand[i] = (unsigned short) FK_HL;
@@ -1494,16 +1504,90 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     const u32 slot = it & 3u;
     if (wave == 0) {
       if (tile + FK_GROUP == grp_end) { if (lane == 0) T.grp[gpar ^ 1u] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP); }
-      if (lane == 0) T.ncand[(it + 2u) & 3u] = 0;        // (zeroed two tiles ahead)
+      if (lane == 0) { T.ncand[(it + 2u) & 3u] = 0; T.ncand2 = 0; }      // (zeroed two tiles ahead; the second chance's: a barrier ahead)
     }
-    u32 S32 = 0, L32 = 0;
+    u32 S32 = 0, L32 = 0, N32 = 0;
     const u32 pred_now = pred;
+    u32 x[8];
+    // ---- phase 1: 32 bytes per lane -> codes, run starts, letters ---------------------------------------------
+    // (with_n: the tile's second chance, see below -- 'N' is let through and its positions are gathered as well)
+    auto classify = [&] (auto with_n) -> u32 {
+      constexpr bool NP = decltype (with_n)::value;
+      // the word in front: the last word of the lane before (one DPP move); the wave's first lane has it from `pred`
+      const u32 prevw = (u32) __builtin_amdgcn_update_dpp ((int) pred_now, (int) x[7], 0x138, 0xF, 0xF, false);   // wave_shr:1
+      u32 selp = prevw & M07, bad = 0, r[8], sc[4] = {0, 0, 0, 0}, lc[4] = {0, 0, 0, 0}, nc[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const u32 w = x[j];
+        const u32 sel = w & M07;
+        // every byte must be the table's entry for its low three bits: 1 'A', 2 '\n', 3 'C', 4 'T', 7 'G' (entries 0, 5, 6
+        // hold bytes with other low bits: they can never match; the second chance has 'N' at 6)
+        const u32 rec = __builtin_amdgcn_perm (NP ? 0x474E0054u : 0x47000054u, 0x430A4101u, sel);
+        bad = __builtin_amdgcn_bitop3_b32 (bad, w, rec, BITOP3_OR_XOR);
+        // 2-bit code = bits 1-2 of b ^ (b >> 1) (A 0, C 1, G 2, T 3; N 0), gathered 4 bytes -> 8 bits (twice the value: the codes sit at bit 1)
+        const u32 cd = __builtin_amdgcn_bitop3_b32 (w, M06, w >> 1, BITOP3_XOR_AND);
+        r[j] = __builtin_amdgcn_udot4 (cd, 0x40100401u, 0u, false);
+        // letters have bit 6 ('\n' has not): 64 x the byte of 8 flags per pair of words
+        const u32 wts = (j & 1) ? 0x80402010u : 0x08040201u;
+        lc[j >> 1] = __builtin_amdgcn_udot4 (w & M40, wts, lc[j >> 1], false);
+        // run start: low three bits differ from the byte before
+        const u32 d = sel ^ __builtin_amdgcn_alignbit (sel, selp, 24);
+        const u32 nz = __builtin_amdgcn_perm (0x01010101u, 0x01010100u, d);       // byte != 0 -> 1
+        sc[j >> 1] = __builtin_amdgcn_udot4 (nz, wts, sc[j >> 1], false);
+        if constexpr (NP) nc[j >> 1] = __builtin_amdgcn_udot4 (__builtin_amdgcn_perm (0x00010000u, 0u, sel), wts, nc[j >> 1], false);
+        selp = sel;
+      }
+      const u32 code_lo = (r[0] >> 1) | (r[1] << 7) | (r[2] << 15) | (r[3] << 23);
+      const u32 code_hi = (r[4] >> 1) | (r[5] << 7) | (r[6] << 15) | (r[7] << 23);
+      S32 = sc[0] | (sc[1] << 8) | (sc[2] << 16) | (sc[3] << 24);
+      L32 = ((lc[0] | (lc[1] << 8)) >> 6) | (((lc[2] | (lc[3] << 8)) >> 6) << 16);
+      *reinterpret_cast<uint2 *> (&T.code[2 * tid]) = make_uint2 (code_lo, code_hi);
+      T.st[tid] = S32;
+      T.lt[tid] = L32;
+      if constexpr (NP) { N32 = nc[0] | (nc[1] << 8) | (nc[2] << 16) | (nc[3] << 24); T.np[tid] = N32; }
+      return bad;
+    };
+    // ---- phase 2: candidate tract starts among this lane's 32 positions ------------------------------------------
+    // (the next lane's run starts come by DPP; the wave's last lane assumes none, i.e. that runs go on: phase 3 checks
+    // the length anyway.)  count_addr: the LDS word that counts the tile's candidates.
+    auto find_candidates = [&] (u32 count_addr, bool n_tile) {
+      const u32 nx = (u32) __builtin_amdgcn_update_dpp (0, (int) S32, 0x130, 0xF, 0xF, false);   // wave_shl:1
+      u32 cand = S32 & L32 & own;
+      // no run start at the next mprime - 1 positions (the usual minimum lengths without a loop: its scalar bookkeeping
+      // costs more than the vector work)
+      {
+        const u32 a1 = __builtin_amdgcn_alignbit (nx, S32, 1u), a2 = __builtin_amdgcn_alignbit (nx, S32, 2u);
+        if (mprime == 3) cand = cand & ~(a1 | a2);
+        else if (mprime == 2) cand = cand & ~a1;
+        else if (mprime == 4) cand = cand & ~(a1 | a2 | __builtin_amdgcn_alignbit (nx, S32, 3u));
+        else for (int j = 1; j < mprime; j++) cand &= ~__builtin_amdgcn_alignbit (nx, S32, (u32) j);
+      }
+      // (a run of 'N' long enough to count takes its context from the tract before it, reference src/hopo_counter.c:246-248:
+      // the general kernel's business)
+      if (n_tile && (cand & N32)) T.ncand2 = 0x40000000u;
+      const u32 n = (u32) __popc (cand);
+      const u32 incl = wave_inclusive_scan (n);
+      const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, 63);
+      u32 wraw;
+      lds_add_issue (count_addr, total, wraw);
+      const u32 p0 = (u32) (FK_UNIT * tid);
+      const u32 wbase = lds_collect (wraw);
+      // (a wave whose candidates would not all fit leaves its list alone: the tile is given up below)
+      if (wbase + total <= (u32) FK_MAXCAND) {
+        u32 at = wbase + incl - n;
+        while (cand) {
+          const u32 b = (u32) __ffs ((int) cand) - 1u;
+          cand &= cand - 1u;
+          T.cand[at] = (unsigned short) (p0 | b);
+          at++;
+        }
+      }
+    };
     {
-      // ---- phase 1: 32 bytes per lane -> codes, run starts, letters -------------------------------------------
       asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has landed in raw
       STAMP (1);
       const uint4 va = raw[2 * tid], vb = raw[2 * tid + 1];
-      u32 x[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+      x[0] = va.x; x[1] = va.y; x[2] = va.z; x[3] = va.w; x[4] = vb.x; x[5] = vb.y; x[6] = vb.z; x[7] = vb.w;
       if (!((u32) (tile - 1) < (u32) t_hi)) {            // (uniform; the stream's first and last tiles) chunks that are not wholly inside the stream: byte by byte
         const long p0 = tile * (long) FK_OWN - FK_HL + 32l * tid;
 #pragma unroll
@@ -1515,37 +1599,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
           }
         }
       }
-      // the word in front: the last word of the lane before (one DPP move); the wave's first lane has it from `pred`
-      const u32 prevw = (u32) __builtin_amdgcn_update_dpp ((int) pred_now, (int) x[7], 0x138, 0xF, 0xF, false);   // wave_shr:1
-      u32 selp = prevw & M07, bad = 0, r[8], sc[4] = {0, 0, 0, 0}, lc[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const u32 w = x[j];
-        const u32 sel = w & M07;
-        // every byte must be the table's entry for its low three bits: 1 'A', 2 '\n', 3 'C', 4 'T', 7 'G' (entries 0, 5, 6
-        // hold bytes with other low bits: they can never match)
-        const u32 rec = __builtin_amdgcn_perm (0x47000054u, 0x430A4101u, sel);
-        bad = __builtin_amdgcn_bitop3_b32 (bad, w, rec, BITOP3_OR_XOR);
-        // 2-bit code = bits 1-2 of b ^ (b >> 1) (A 0, C 1, G 2, T 3), gathered 4 bytes -> 8 bits (twice the value: the codes sit at bit 1)
-        const u32 cd = __builtin_amdgcn_bitop3_b32 (w, M06, w >> 1, BITOP3_XOR_AND);
-        r[j] = __builtin_amdgcn_udot4 (cd, 0x40100401u, 0u, false);
-        // letters have bit 6 ('\n' has not): 64 x the byte of 8 flags per pair of words
-        const u32 wts = (j & 1) ? 0x80402010u : 0x08040201u;
-        lc[j >> 1] = __builtin_amdgcn_udot4 (w & M40, wts, lc[j >> 1], false);
-        // run start: low three bits differ from the byte before
-        const u32 d = sel ^ __builtin_amdgcn_alignbit (sel, selp, 24);
-        const u32 nz = __builtin_amdgcn_perm (0x01010101u, 0x01010100u, d);       // byte != 0 -> 1
-        sc[j >> 1] = __builtin_amdgcn_udot4 (nz, wts, sc[j >> 1], false);
-        selp = sel;
-      }
-      const u32 code_lo = (r[0] >> 1) | (r[1] << 7) | (r[2] << 15) | (r[3] << 23);
-      const u32 code_hi = (r[4] >> 1) | (r[5] << 7) | (r[6] << 15) | (r[7] << 23);
-      S32 = sc[0] | (sc[1] << 8) | (sc[2] << 16) | (sc[3] << 24);
-      L32 = ((lc[0] | (lc[1] << 8)) >> 6) | (((lc[2] | (lc[3] << 8)) >> 6) << 16);
-      *reinterpret_cast<uint2 *> (&T.code[2 * tid]) = make_uint2 (code_lo, code_hi);
-      T.st[tid] = S32;
-      T.lt[tid] = L32;
-      if (bad) T.ncand[slot] = 0x40000000u;              // (more candidates than any tile has: given up below; later atomic adds keep it so)
+      if (classify (std::false_type ())) T.ncand[slot] = 0x40000000u;   // (more candidates than any tile has: looked at below; later atomic adds keep it so)
     }
     STAMP (2);
     // the tile after this one
@@ -1559,39 +1613,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     if (S32 == 0x12345u && L32 == 0x54321u) T.bad[3] = 1u;
     S32 = 0;
 #endif
-    {
-      // ---- phase 2: candidate tract starts among this lane's 32 positions ----------------------------------
-      // (the next lane's run starts come by DPP; the wave's last lane assumes none, i.e. that runs go on: phase 3
-      // checks the length anyway)
-      const u32 nx = (u32) __builtin_amdgcn_update_dpp (0, (int) S32, 0x130, 0xF, 0xF, false);   // wave_shl:1
-      u32 cand = S32 & L32 & own;
-      // no run start at the next mprime - 1 positions (the usual minimum lengths without a loop: its scalar bookkeeping
-      // costs more than the vector work)
-      {
-        const u32 a1 = __builtin_amdgcn_alignbit (nx, S32, 1u), a2 = __builtin_amdgcn_alignbit (nx, S32, 2u);
-        if (mprime == 3) cand = cand & ~(a1 | a2);
-        else if (mprime == 2) cand = cand & ~a1;
-        else if (mprime == 4) cand = cand & ~(a1 | a2 | __builtin_amdgcn_alignbit (nx, S32, 3u));
-        else for (int j = 1; j < mprime; j++) cand &= ~__builtin_amdgcn_alignbit (nx, S32, (u32) j);
-      }
-      const u32 n = (u32) __popc (cand);
-      const u32 incl = wave_inclusive_scan (n);
-      const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, 63);
-      u32 wraw;
-      lds_add_issue (ncand_addr + 4u * slot, total, wraw);
-      const u32 p0 = (u32) (FK_UNIT * tid);
-      const u32 wbase = lds_collect (wraw);
-      // (a wave whose candidates would not all fit leaves its list alone: the tile is given up below)
-      if (wbase + total <= (u32) FK_MAXCAND) {
-        u32 at = wbase + incl - n;
-        while (cand) {
-          const u32 b = (u32) __ffs ((int) cand) - 1u;
-          cand &= cand - 1u;
-          T.cand[at] = (unsigned short) (p0 | b);
-          at++;
-        }
-      }
-    }
+    find_candidates (ncand_addr + 4u * slot, false);
     STAMP (4);
 #if !(defined(FK_EXP_NOBAR) && (FK_EXP_NOBAR & 2))
     lds_barrier ();
@@ -1604,7 +1626,22 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #else
     const u32 ncand_all = (u32) __builtin_amdgcn_readfirstlane ((int) T.ncand[slot]);
 #endif
-    const bool give_up = ncand_all > (u32) FK_MAXCAND;    // (or a byte outside the alphabet)
+    u32 ncand_now = ncand_all;
+    if (ncand_all >= 0x40000000u) {
+      // Second chance for a tile with a byte outside the five: if all such bytes are 'N' (the no-call of every sequencer),
+      // classify again with 'N' let through (it packs as code 0 like 'A' -- what the reference's table gives it in a flank
+      // read forwards), gather where the 'N's are, find the candidates again, and let phase 3 read the tracts that have
+      // one within their 2k + length positions from the stream.  Anything else -- lower case, U, IUPAC codes, a countable
+      // run of 'N' -- still sends the tile to the general kernel.  (The bytes are still in registers; the tile costs
+      // two more barriers and a second classification, a fraction of what the general kernel takes for it.)
+      const u32 bad2 = classify (std::true_type ());
+      if (bad2) T.ncand2 = 0x40000000u;
+      lds_barrier ();
+      find_candidates ((u32) (size_t) (lptr_t) &T.ncand2, true);
+      lds_barrier ();
+      ncand_now = (u32) __builtin_amdgcn_readfirstlane ((int) T.ncand2);
+    }
+    const bool give_up = ncand_now > (u32) FK_MAXCAND;    // (too many candidates, or a byte that is not for this kernel)
     if (give_up) {
       // (listed in batches: one atomic with a return value per tile, on one address for the whole grid, cost 4.6 us each
       // when every tile of a stream was given up -- more than scanning the tile)
@@ -1612,7 +1649,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       if (++n_sbuf == 32u) flush_slow ();
     }
     else {
-      const int ncand = (int) ncand_all;
+      const int ncand = (int) ncand_now;
       if constexpr (W != 1) {                           // k > 12: two windows per plane (the flanks do not fit one with the tract)
         const long g0 = tile * (long) FK_OWN - FK_HL;
         for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
@@ -1622,7 +1659,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
           bool have = false;
           u64 c0 = 0, c1 = 0;
           u32 base = 0, len10 = 0, flag = 0;
-          if (ci < ncand) have = fast_tract<false> (T, seq, n_bytes, g0, (int) T.cand[ci], k, mprime, c0, c1, base, len10, flag);
+          if (ci < ncand) have = fast_tract<false> (T, seq, n_bytes, g0, (int) T.cand[ci], k, mprime, c0, c1, base, len10, flag, (ncand_all >= 0x40000000u));
           const u64 okm = __builtin_amdgcn_ballot_w64 (have);
           u32 araw;
           lds_add_issue (sink.count_addr (), (u32) __builtin_popcountll (okm), araw);
@@ -1655,9 +1692,10 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         const bool general = valid && need > 32u;
         const u32 notl = ~__builtin_amdgcn_alignbit (l1, l0, u);
         bool ok = valid && (need <= 32u) && ((notl << ((v32 - need) & 31u)) == 0u) && (len >= vmp);
+
         u32 glo = 0, ghi = 0;
         if (general) {
-          const u64 rec = fast_general_tract (T, seq, n_bytes, tile * (long) FK_OWN - FK_HL, (int) s, k, mprime);
+          const u64 rec = fast_general_tract (T, seq, n_bytes, tile * (long) FK_OWN - FK_HL, (int) s, k, mprime, (ncand_all >= 0x40000000u));
           ok = rec != 0ull; glo = (u32) rec; ghi = (u32) (rec >> 32);
         }
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
@@ -1675,7 +1713,14 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         const u32 cb = (clo >> vk2) & 3u;                  // the tract's base
         const u32 r = (u32) ((((u64) chi << 32) | clo) >> (vk2 + len + len)) & vkm;
         // canonical orientation (reference: src/hopo_counter.c:233-246): T / G tracts store the reverse complement
-        const u32 rcl = revcomp_v32 (l, M55, vrs), rcr = revcomp_v32 (r, M55, vrs);
+        u32 rcl = revcomp_v32 (l, M55, vrs), rcr = revcomp_v32 (r, M55, vrs);
+        if ((ncand_all >= 0x40000000u)) {                                       // (uniform) 'N's in the flanks: forward code 3 where the strand is turned (see fast_tract)
+          const u32 nb = bits32 (T.np, (int) u);
+          if ((nb << ((v32 - need) & 31u)) != 0u && need <= 32u) {
+            rcl = revcomp_v32 (l | (u32) spread_pairs (nb & ((1u << k) - 1u)), M55, vrs);
+            rcr = revcomp_v32 (r | (u32) spread_pairs ((nb >> ((u32) k + len)) & ((1u << k) - 1u)), M55, vrs);
+          }
+        }
         const bool rev = cb >= 2u;
         const u32 c0 = rev ? rcr : l, c1 = rev ? rcl : r;
         // base << 2 | flag << 3 by table look-up on cb: A (0, fwd) 8, C (1, fwd) 12, G (-> C, rev) 20, T (-> A, rev) 16

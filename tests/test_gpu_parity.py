@@ -304,6 +304,27 @@ def test_finalise_synthetic(k, m, rb, mc):
     assert st == 0 and n > 0
 
 
+@pytest.mark.parametrize("k,m", [(10, 3), (12, 2), (15, 4), (31, 3)])
+def test_streams_with_no_calls_match_the_oracle(k, m):
+    # 'N' is what real reads hold besides ACGT.  The fast kernel gives a tile with one a second classification (N let
+    # through, an N plane for the flanks read backwards) and leaves only countable runs of N -- and every other byte -- to
+    # the general kernel; whichever kernel takes a tile, the records are the oracle's
+    s = tj.synth_stream(60000, 150, 200000).copy()        # ~550 fast-kernel tiles, depth 45
+    rng = np.random.default_rng(k * 100 + m)
+    reads = rng.choice(60000, 3000, replace=False)
+    s[reads[:2400] * 151 + rng.integers(0, 150, 2400)] = ord("N")                 # isolated no-calls
+    for r in reads[2400:2800]:                                                    # runs of N (stale-context rule)
+        p, n = int(rng.integers(0, 140)), int(rng.integers(2, 9))
+        s[r * 151 + p: r * 151 + min(p + n, 150)] = ord("N")
+    for r in reads[2800:]:                                                        # lower case, U, IUPAC codes
+        p = int(rng.integers(0, 147))
+        s[r * 151 + p: r * 151 + p + 3] = np.frombuffer(rng.choice([b"acg", b"UUU", b"RYK", b"nnn", b"tTt"]), np.uint8)
+    n = check_raw_multiset(s, k, m)
+    assert n > 10000
+    st, kept = check_finalise([s], k, m, 1, 3)
+    assert st == 0 and kept > 100
+
+
 @pytest.mark.parametrize("k,m,limit", [(10, 3, 1), (25, 4, 2), (32, 3, 1), (2, 1, 1)])
 def test_finalise_radix_fallback(monkeypatch, k, m, limit):
     # the kept set is ordered by a bin partition + rank sort; a bin fuller than the limit must switch the whole sort to
