@@ -3500,8 +3500,11 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
   const int par = (int) (c->scan_seq++ & 1u);            // per-launch counters are double-buffered (DevCounters::lc)
   if (first) HIPCHK (hipEventRecord (c->ev_s0, c->stream));
   const TileSrc plain = {nullptr, 0};
+  // (the fast kernel counts tiles and bytes in 32 bits: a piece that could not be cut below 2 GiB -- one read longer
+  // than that -- is left to the general kernel)
+  const bool use_fast = c->fast_mode && n_bytes < ((size_t) 1 << 31) - (1u << 20);
 #define TJ_LAUNCH_SCAN(WW) do { \
-    if (c->fast_mode) { \
+    if (use_fast) { \
       /* the fast kernel takes every tile it can vouch for and lists the others; the generic kernel then works through the list */ \
       hipLaunchKernelGGL (scan_fast_kernel<WW>, dim3 (fgrid), dim3 (FK_BLOCK), 0, c->stream, seq, (long) n_bytes, n_ftiles, c->k, mprime, BK, c->d_ctr, \
                           (u32 *) c->slow.p, par, c->fast_mode == 2 ? 1 : 0); \
@@ -3531,9 +3534,10 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
 // storage then follows what the reads really contain instead of the worst case of the whole stream (n / m' records).
 
 __global__ __launch_bounds__ (1024)
-void find_cut_kernel (const uint8_t *__restrict__ seq, unsigned long long from, unsigned long long n, unsigned long long *out)
-{ // *out = smallest p >= from with p % 16 == 15 and seq[p] == '\n', or ~0
+void find_cut_kernel (const uint8_t *__restrict__ seq, unsigned long long first_from, unsigned long long step, unsigned long long n, unsigned long long *out)
+{ // out[b] = smallest p >= first_from + b * step with p % 16 == 15 and seq[p] == '\n', or ~0 (one workgroup per cut)
   __shared__ unsigned long long best;
+  const unsigned long long from = first_from + (unsigned long long) blockIdx.x * step;
   if (threadIdx.x == 0) best = ~0ull;
   __syncthreads ();
   for (unsigned long long base = from & ~15ull; base < n; base += 1024ull * 16ull) {
@@ -3543,7 +3547,7 @@ void find_cut_kernel (const uint8_t *__restrict__ seq, unsigned long long from, 
     if (best != ~0ull) break;
     __syncthreads ();
   }
-  if (threadIdx.x == 0) *out = best;
+  if (threadIdx.x == 0) out[blockIdx.x] = best;
 }
 
 extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t n_bytes, int min_tract_size)
@@ -3556,19 +3560,24 @@ extern "C" int tjamd_scan_device (tjamd_counter *c, const void *d_stream, size_t
   const size_t piece_target = c->piece_target, piece_max = piece_target + piece_target / 2;
   if (n_bytes <= piece_max) return scan_device_piece (c, d_stream, n_bytes, min_tract_size, true, true);
   const uint8_t *seq = (const uint8_t *) d_stream;
-  size_t off = 0;
-  bool first = true;
-  rc = ensure (c->prefix, 64, c->stream);
+  // every piece is cut near a multiple of the target: the cuts do not depend on each other, so they are all looked for
+  // by one launch and fetched with one copy (per piece that would be a kernel, a copy and a synchronisation of 25 us)
+  const size_t n_cuts = (n_bytes - 1) / piece_target;    // candidates at piece_target, 2 piece_target, ...
+  std::vector<unsigned long long> cuts (n_cuts);
+  rc = ensure (c->prefix, 64 + 8 * n_cuts, c->stream);
   if (rc) return rc;
+  hipLaunchKernelGGL (find_cut_kernel, dim3 ((unsigned) n_cuts), dim3 (1024), 0, c->stream, seq, (unsigned long long) piece_target, (unsigned long long) piece_target,
+                      (unsigned long long) n_bytes, (unsigned long long *) c->prefix.p);
+  HIPCHK (hipMemcpyAsync (cuts.data (), c->prefix.p, 8 * n_cuts, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK (hipStreamSynchronize (c->stream));
+  size_t off = 0, next_cut = 0;
+  bool first = true;
   while (off < n_bytes) {
     size_t end = n_bytes;
     if (n_bytes - off > piece_max) {
-      unsigned long long cut = ~0ull;
-      hipLaunchKernelGGL (find_cut_kernel, dim3 (1), dim3 (1024), 0, c->stream, seq, (unsigned long long) (off + piece_target), (unsigned long long) n_bytes,
-                          (unsigned long long *) c->prefix.p);
-      HIPCHK (hipMemcpyAsync (&cut, c->prefix.p, 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK (hipStreamSynchronize (c->stream));
-      if (cut != ~0ull && cut + 1 < n_bytes) end = (size_t) cut + 1;
+      // the next cut that makes a piece of at least half the target (cuts come in increasing order, about a target apart)
+      while (next_cut < n_cuts && (cuts[next_cut] == ~0ull || cuts[next_cut] + 1 < off + piece_target / 2)) next_cut++;
+      if (next_cut < n_cuts && cuts[next_cut] + 1 < n_bytes) end = (size_t) cuts[next_cut] + 1;
     }
     rc = scan_device_piece (c, seq + off, end - off, min_tract_size, first, end == n_bytes);
     if (rc) return rc;
