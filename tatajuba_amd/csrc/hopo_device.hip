@@ -2082,6 +2082,7 @@ struct Agg2Lds
   u32 cnt[2 * AG2_S];                   // per slot: forward / reverse strand
   u32 chunk[AG_NCH];
   u32 n_claimed, n_ovf, total;
+  u32 next_batch;                       // (see aggregate1_kernel: batches are handed to the waves as they come for one)
   u32 wsum[AG_BLOCK / 64];
 };
 
@@ -2100,7 +2101,7 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
 
   while (n > 0) {
     for (int i = tid; i < AG2_S; i += AG_BLOCK) { L.kk[i] = make_ulonglong2 (0ull, 0ull); L.cnt[2 * i] = 0; L.cnt[2 * i + 1] = 0; }
-    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.next_batch = 0; }
     __syncthreads ();
 
     u64 wn[2 * AG2_R];
@@ -2116,7 +2117,7 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       const u64 off0 = (u64) c0 * ch - (u64) j0 * ch, off1 = (u64) c1 * ch - (u64) bound;
 #pragma unroll
       for (int r = 0; r < AG2_R; r++) {
-        const u32 idx = b0 + (u32) r * AG_BLOCK + (u32) tid;
+        const u32 idx = b0 + (u32) r * 64u + (u32) lane;
         const bool hi = idx >= bound;
         if (idx < n && (hi ? c1 : c0) != TJ_NOCHUNK) {
           const ulonglong2 v = *reinterpret_cast<const ulonglong2 *> (src + 2 * ((hi ? off1 : off0) + idx));
@@ -2124,15 +2125,22 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
         }
       }
     };
-    fetch (0u);
-    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK * AG2_R) {
+    auto next_batch = [&] () {
+      u32 b = 0;
+      if (lane == 0) b = atomicAdd (&L.next_batch, 1u);
+      return (u32) __builtin_amdgcn_readfirstlane ((int) b) * (64u * AG2_R);
+    };
+    u32 b_next = next_batch ();
+    fetch (b_next);
+    while (b_next < n) {
       asm volatile ("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(wn[4]), "+v"(wn[5]), "+v"(wn[6]), "+v"(wn[7]) :: "memory");
       static_assert (AG2_R == 4, "asm operand list");
       u64 w[2 * AG2_R];
 #pragma unroll
       for (int r = 0; r < 2 * AG2_R; r++) w[r] = wn[r];
       const u32 valid = vn;
-      fetch (b0 + AG_BLOCK * AG2_R);
+      b_next = next_batch ();
+      fetch (b_next);
       {
         auto home = [] (u64 a, u64 b) {                 // home pair of a key
           const u64 key1 = b & ~(3ull << 61);
