@@ -2313,6 +2313,7 @@ struct Agg4Lds
   u32 cnt[2 * AG4_S];
   u32 chunk[AG_NCH];
   u32 n_claimed, n_ovf, total;
+  u32 next_batch;                       // (see aggregate1_kernel)
   u32 wsum[AG_BLOCK / 64];
 };
 
@@ -2331,7 +2332,7 @@ void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
 
   while (n > 0) {
     for (int i = tid; i < AG4_S; i += AG_BLOCK) { L.cw[i] = 0; L.c0[i] = 0; L.c1[i] = 0; L.cnt[2 * i] = 0; L.cnt[2 * i + 1] = 0; }
-    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; }
+    if (tid == 0) { L.n_claimed = 0; L.n_ovf = 0; L.next_batch = 0; }
     __syncthreads ();
 
     u64 wn[3 * AG4_R];                                  // (the fourth word of a record is padding)
@@ -2347,7 +2348,7 @@ void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       const u64 off0 = (u64) c0 * ch - (u64) j0 * ch, off1 = (u64) c1 * ch - (u64) bound;
 #pragma unroll
       for (int r = 0; r < AG4_R; r++) {
-        const u32 idx = b0 + (u32) r * AG_BLOCK + (u32) tid;
+        const u32 idx = b0 + (u32) r * 64u + (u32) lane;
         const bool hi = idx >= bound;
         if (idx < n && (hi ? c1 : c0) != TJ_NOCHUNK) {
           const u64 *p = src + 4 * ((hi ? off1 : off0) + idx);
@@ -2356,15 +2357,22 @@ void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
         }
       }
     };
-    fetch (0u);
-    for (u32 b0 = 0; b0 < n; b0 += AG_BLOCK * AG4_R) {
+    auto next_batch = [&] () {
+      u32 b = 0;
+      if (lane == 0) b = atomicAdd (&L.next_batch, 1u);
+      return (u32) __builtin_amdgcn_readfirstlane ((int) b) * (64u * AG4_R);
+    };
+    u32 b_next = next_batch ();
+    fetch (b_next);
+    while (b_next < n) {
       asm volatile ("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2]), "+v"(wn[3]), "+v"(wn[4]), "+v"(wn[5]) :: "memory");
       static_assert (AG4_R == 2, "asm operand list");
       u64 w[3 * AG4_R];
 #pragma unroll
       for (int r = 0; r < 3 * AG4_R; r++) w[r] = wn[r];
       const u32 valid = vn;
-      fetch (b0 + AG_BLOCK * AG4_R);
+      b_next = next_batch ();
+      fetch (b_next);
       u32 todo = 0;
 #pragma unroll
       for (int q = 0; q < AG4_R; q++) if (((valid >> q) & 1u) && ((w[3 * q + 2] >> 12) & 3ull) != 3ull) todo |= 1u << q;
