@@ -113,6 +113,10 @@ struct FixEntry { long long pos; long long len; };
 
 // counts of the finalise step (device block read back by the host)
 struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow, sort_fallback, pad; };
+// The sizes the ordering kernels work with, derived on the device from the number of kept records so that the host does
+// not have to fetch that number between the aggregation and them (plan_kernel; ok = 0: nothing to do, or more records
+// than the buffers were sized for -- every kernel then returns at once and the host takes the exact path).
+struct FinPlan { long n1; long t; int nbits, nbins, log2t, ok; u32 kept_overflow, pad; };
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2623,8 +2627,10 @@ __device__ __forceinline__ u32 bin_reserve (u32 *__restrict__ cursors, u32 bin, 
 }
 
 __global__ __launch_bounds__ (256)
-void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32 *__restrict__ bins, uint4 *__restrict__ cov, long cov_vec, int grouped)
+void bin_count_kernel (const u64 *__restrict__ in, long n, int k, int nbits, u32 *__restrict__ bins, uint4 *__restrict__ cov, long cov_vec, int grouped,
+                       const FinPlan *__restrict__ plan = nullptr)
 { // (also empties the coverage table, which the sort pass three launches later fills: 16 bytes per store)
+  if (plan) { if (!plan->ok) return; n = plan->n1; nbits = plan->nbits; cov_vec = plan->t / 2; }
   for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < cov_vec; i += (long) gridDim.x * 256) cov[i] = make_uint4 (0, 0, 0, 0);
   for (long i0 = (long) blockIdx.x * 256; i0 < n; i0 += (long) gridDim.x * 256) {     // (wave-uniform trip count: ballots inside)
     const long i = i0 + threadIdx.x;
@@ -2675,17 +2681,20 @@ __device__ __forceinline__ u32 wg_exclusive_scan (const u32 *__restrict__ in, in
 // bin counts -> binstart[0..nbins] and the scatter cursors (bins[] itself); a bin above rank_max switches the whole
 // sort to the radix path (flag in FinCounts)
 __global__ __launch_bounds__ (1024)
-void bin_scan_kernel (u32 *__restrict__ bins, int nbins, u32 *__restrict__ binstart, u32 rank_max, FinCounts *fin)
+void bin_scan_kernel (u32 *__restrict__ bins, int nbins, u32 *__restrict__ binstart, u32 rank_max, FinCounts *fin, const FinPlan *__restrict__ plan = nullptr)
 {
   __shared__ WgScanLds L;
   u32 vmax;
+  if (plan) { if (!plan->ok) return; nbins = plan->nbins; }
   const u32 total = wg_exclusive_scan (bins, nbins, binstart, bins, L, vmax);
   if (threadIdx.x == 0) { binstart[nbins] = total; fin->sort_fallback = vmax > rank_max ? 1u : 0u; }
 }
 
 __global__ __launch_bounds__ (256)
-void bin_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, long n, int k, int nbits, u32 *__restrict__ cursors)
+void bin_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, long n, int k, int nbits, u32 *__restrict__ cursors,
+                         const FinPlan *__restrict__ plan = nullptr)
 {
+  if (plan) { if (!plan->ok) return; n = plan->n1; nbits = plan->nbits; }
   for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < n; i += (long) gridDim.x * 256) {
     const u64 *p = in + 3 * i;
     const u64 a = p[0], b = p[1], m = p[2];
@@ -2882,10 +2891,11 @@ void cov_max_kernel (const u64 *__restrict__ tab, long t, int *result)
 __global__ __launch_bounds__ (64 * BSI_WAVES)
 void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, const u32 *__restrict__ binstart, int nbins, const FinCounts *fin,
                             int min_coverage, u64 *__restrict__ cov_tab, int log2t,
-                            u32 *__restrict__ binctx, u32 *__restrict__ tstart, u32 *__restrict__ tend)
+                            u32 *__restrict__ binctx, u32 *__restrict__ tstart, u32 *__restrict__ tend, const FinPlan *__restrict__ plan = nullptr)
 {
   __shared__ u64 rec[BSI_WAVES][3 * BS_RANK_MAX];
   __shared__ u32 hd[BSI_WAVES][BS_RANK_MAX], sz[BSI_WAVES][BS_RANK_MAX];
+  if (plan) { if (!plan->ok) return; nbins = plan->nbins; log2t = plan->log2t; }
   if (fin->sort_fallback) return;                       // some bin is too full: the caller takes the radix path
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u64 *R = rec[wave];
@@ -2944,10 +2954,11 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
 
 // one workgroup: exclusive prefix of binctx -> binout, number of index ranges, coverage start value
 __global__ __launch_bounds__ (1024)
-void bin_ctx_scan_kernel (const u32 *__restrict__ binctx, int nbins, u32 *__restrict__ binout, FinCounts *fin)
+void bin_ctx_scan_kernel (const u32 *__restrict__ binctx, int nbins, u32 *__restrict__ binout, FinCounts *fin, const FinPlan *__restrict__ plan = nullptr)
 {
   __shared__ WgScanLds L;
   u32 vmax;
+  if (plan) { if (!plan->ok) return; nbins = plan->nbins; }
   const u32 total = wg_exclusive_scan (binctx, nbins, binout, nullptr, L, vmax);
   if (threadIdx.x == 0 && !fin->sort_fallback) { fin->n_idx = total; fin->coverage = INT_MIN; }
 }
@@ -2956,9 +2967,10 @@ void bin_ctx_scan_kernel (const u32 *__restrict__ binctx, int nbins, u32 *__rest
 __global__ __launch_bounds__ (256)
 void bin_ctx_write_kernel (const u32 *__restrict__ binstart, const u32 *__restrict__ binctx, const u32 *__restrict__ binout, int nbins,
                            const u32 *__restrict__ tstart, const u32 *__restrict__ tend, int *__restrict__ idx_initial, int *__restrict__ idx_final,
-                           const u64 *__restrict__ cov_tab, long t, FinCounts *fin)
+                           const u64 *__restrict__ cov_tab, long t, FinCounts *fin, const FinPlan *__restrict__ plan = nullptr)
 {
   __shared__ int s_best[4];
+  if (plan) { if (!plan->ok) return; nbins = plan->nbins; t = plan->t; }
   if (fin->sort_fallback) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int bin = blockIdx.x * 4 + wave; bin < nbins; bin += gridDim.x * 4) {
@@ -3152,7 +3164,7 @@ struct DevBuf
 
 // everything the host reads back: one device block, one pinned mirror
 // (each part on cache lines of its own: the scan's workgroups hammer ctr and cursors with atomics)
-struct DevState { alignas (256) DevCounters ctr; alignas (256) FinCounts fin; alignas (256) u32 cursors[TJ_P + 1]; alignas (256) u32 pad[4]; };
+struct DevState { alignas (256) DevCounters ctr; alignas (256) FinCounts fin; alignas (256) u32 cursors[TJ_P + 1]; alignas (256) FinPlan plan; alignas (256) u32 pad[4]; };
 
 struct tjamd_counter
 {
@@ -3772,7 +3784,23 @@ static unsigned grid_for (long n) { return (unsigned) std::max<long> (1, std::mi
 
 // ---- finalise steps 3-4 + coverage, two ways --------------------------------------------------------------------
 
-static int cov_table_bits (long n1) { int b = 10; while ((1l << b) < 4 * n1 && b < 31) b++; return b; }   // 2 n1 entries at most: half full
+__host__ __device__ static inline int cov_table_bits (long n1) { int b = 10; while ((1l << b) < 4 * n1 && b < 31) b++; return b; }   // 2 n1 entries at most: half full
+__host__ __device__ static inline int bin_bits_for (long n1, int k)
+{
+  int nbits = 6;
+  while (nbits < BS_MAXBITS && nbits < 1 + 4 * k && (48l << nbits) < n1) nbits++;    // ~24..48 records per bin: most of a wavefront's lanes busy
+  return nbits < 1 + 4 * k ? nbits : 1 + 4 * k;
+}
+// the ordering step's sizes from the kept count the aggregation has just produced (the host launches the ordering kernels
+// without knowing it; `cap` = records its buffers hold)
+__global__ void plan_kernel (const FinCounts *__restrict__ fin, int k, long cap, FinPlan *__restrict__ plan)
+{
+  const long n1 = (long) fin->n_kept;
+  plan->n1 = n1; plan->kept_overflow = fin->overflow;
+  plan->nbits = bin_bits_for (n1, k); plan->nbins = 1 << plan->nbits;
+  plan->log2t = cov_table_bits (n1); plan->t = 1l << plan->log2t;
+  plan->ok = (n1 > 0 && n1 <= cap && !fin->overflow) ? 1 : 0;
+}
 
 // radix path: stable LSD sort, then heads / scans / decisions as separate kernels (any bin occupancy, any size)
 static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
@@ -3836,12 +3864,16 @@ static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
 // binned path: kept (n1 records, any order) -> sorted kept, idx_i / idx_f, FinCounts{n_idx, coverage}; one host
 // synchronisation at the end.  If a bin turns out too full every kernel after the bin scan does nothing, kept stays as
 // it was and FinCounts::sort_fallback comes back set.
-static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
+// n1 > 0: the kept count, known.  n1 == 0: not fetched yet -- the kernels take their sizes from the device-side plan
+// (plan_kernel has run), the buffers hold `cap` records, and the caller looks at what came of it after the one
+// synchronisation at the end (finalise_speculative_ok).
+static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long cap = 0)
 {
-  int nbits = 6;
-  while (nbits < BS_MAXBITS && nbits < 1 + 4 * c->k && (48l << nbits) < n1) nbits++;   // ~24..48 records per bin: most of a wavefront's lanes busy
-  nbits = std::min (nbits, 1 + 4 * c->k);
-  const int nbins = 1 << nbits;
+  const bool planned = n1 == 0;
+  const FinPlan *plan = planned ? &c->d_state->plan : nullptr;
+  if (planned) n1 = cap;                                // (sizes everything below; the kernels use the plan's numbers)
+  const int nbits = bin_bits_for (n1, c->k);
+  const int nbins = planned ? BS_MAXBINS : 1 << nbits;  // (planned: the layout of binctx / binout must not depend on the count)
   const int log2t = cov_table_bits (n1);
   const long t = 1l << log2t;
   int rc = ensure (c->alt, (size_t) n1 * 24, c->stream);
@@ -3859,16 +3891,18 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage)
   u64 *ctab = (u64 *) c->cov.p;
   if (!c->bins_zeroed) HIPCHK (hipMemsetAsync (bins, 0, (size_t) BS_MAXBINS * 4, c->stream));
   c->bins_zeroed = false;
-  hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n1, c->k, nbits, bins,
-                      (uint4 *) c->cov.p, (long) (t / 2), 0);
-  hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, bins, nbins, binstart, c->bin_rank_max, c->d_fin);
-  hipLaunchKernelGGL (bin_scatter_kernel, dim3 (grid_for (n1)), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins);
+  // (planned: the grids are sized for a typical kept count, not for the buffers' capacity -- the kernels stride)
+  const unsigned g1 = planned ? std::min<unsigned> (grid_for (n1), 2048u) : grid_for (n1);
+  hipLaunchKernelGGL (bin_count_kernel, dim3 (g1), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n1, c->k, nbits, bins,
+                      (uint4 *) c->cov.p, (long) (t / 2), 0, plan);
+  hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, bins, nbins, binstart, c->bin_rank_max, c->d_fin, plan);
+  hipLaunchKernelGGL (bin_scatter_kernel, dim3 (g1), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins, plan);
   hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 16384)), dim3 (64 * BSI_WAVES), 0, c->stream,
                       (const u64 *) c->alt.p, (u64 *) c->kept.p, (const u32 *) binstart, nbins, (const FinCounts *) c->d_fin, min_coverage,
-                      ctab, log2t, binctx, tstart, tend);
-  hipLaunchKernelGGL (bin_ctx_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, (const u32 *) binctx, nbins, binout, c->d_fin);
+                      ctab, log2t, binctx, tstart, tend, plan);
+  hipLaunchKernelGGL (bin_ctx_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, (const u32 *) binctx, nbins, binout, c->d_fin, plan);
   hipLaunchKernelGGL (bin_ctx_write_kernel, dim3 (256), dim3 (256), 0, c->stream, (const u32 *) binstart, (const u32 *) binctx, (const u32 *) binout, nbins,
-                      (const u32 *) tstart, (const u32 *) tend, (int *) c->idx_i.p, (int *) c->idx_f.p, (const u64 *) ctab, t, c->d_fin);
+                      (const u32 *) tstart, (const u32 *) tend, (int *) c->idx_i.p, (int *) c->idx_f.p, (const u64 *) ctab, t, c->d_fin, plan);
   HIPCHK (hipGetLastError ());
   HIPCHK (hipEventRecord (c->ev_f1, c->stream));
   c->fin_timed = true;
@@ -3911,10 +3945,21 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   HIPCHK (hipGetLastError ());
   // counters, bucket sizes and the aggregation's own counts, in one copy; then the buckets are emptied (the aggregation
   // consumed them: leftover rounds reuse their fronts) together with the counts the next aggregation adds to
+  // The ordering step is launched right behind, sized on the device (plan_kernel) for up to kept_cap / 8 records -- a sample
+  // keeps a per cent or so of its raw records -- so that the whole finalise has one host round trip; if more were kept, its
+  // kernels do nothing and the step is run again below with the count in hand.
+  long plan_cap = (long) std::min<u64> (kept_cap, std::max<u64> (kept_cap / 8, 1u << 16));
+  if (const char *pc = getenv ("TATAJUBA_AMD_PLAN_CAP")) plan_cap = std::max (1l, std::min (plan_cap, atol (pc)));     // (tests: make the second attempt happen)
+  const bool plan_ahead = speculative && getenv ("TATAJUBA_AMD_NO_PLAN") == nullptr;
+  if (plan_ahead) {
+    hipLaunchKernelGGL (plan_kernel, dim3 (1), dim3 (1), 0, c->stream, (const FinCounts *) c->d_fin, c->k, plan_cap, &c->d_state->plan);
+    HIPCHK (hipGetLastError ());
+  }
   rc = queue_counter_copies (c);
   if (!rc) rc = clear_buckets (c);
   if (rc) return rc;
-  HIPCHK (hipStreamSynchronize (c->stream));
+  if (plan_ahead) { rc = finalise_binned (c, 0, min_coverage, plan_cap); if (rc) return rc; }   // (ends with a copy of the counts and a synchronisation)
+  else HIPCHK (hipStreamSynchronize (c->stream));
   if (speculative) {
     rc = apply_counter_copies (c);
     const long n = c->n_raw_known;
@@ -3923,8 +3968,8 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
     if (n == 0) { c->status = 1; if (status) *status = 1; return TJAMD_OK; }                // reference: src/hopo_counter.c:345-349
     if (n >= (1l << 31)) return set_err (TJAMD_ERR_CAPACITY, "%ld raw records exceed the reference's int n_elem", n);
   }
-  if (c->h_fin->overflow) return set_err (TJAMD_ERR_CAPACITY, "kept list overflow");
-  const long n1 = c->h_fin->n_kept;
+  if (plan_ahead ? c->h_state->plan.kept_overflow : c->h_fin->overflow) return set_err (TJAMD_ERR_CAPACITY, "kept list overflow");
+  const long n1 = plan_ahead ? c->h_state->plan.n1 : (long) c->h_fin->n_kept;
   if (n1 == 0) {                                                               // reference :376-381
     HIPCHK (hipEventRecord (c->ev_f1, c->stream)); c->fin_timed = true;
     c->status = 2; if (status) *status = 2; return TJAMD_OK;
@@ -3933,7 +3978,7 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   // steps 3-4 + coverage: bin partition, then one pass per bin sorts it and derives the context index ranges and the
   // coverage table entries; the stable radix passes + separate index kernels take over if a bin is too full.
   c->n_kept = n1;
-  rc = finalise_binned (c, n1, min_coverage);
+  if (!(plan_ahead && c->h_state->plan.ok)) rc = finalise_binned (c, n1, min_coverage);   // (not done yet, or more kept than planned for)
   if (!rc && c->h_fin->sort_fallback) rc = finalise_radix (c, n1, min_coverage);
   if (rc) return rc;
   c->n_idx = (int) c->h_fin->n_idx;

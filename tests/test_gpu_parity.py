@@ -325,6 +325,21 @@ def test_streams_with_no_calls_match_the_oracle(k, m):
     assert st == 0 and kept > 100
 
 
+@pytest.mark.parametrize("plan", ["cap", "off"])
+def test_finalise_when_more_is_kept_than_planned_for(monkeypatch, plan):
+    # the ordering step is launched before the host knows how many records were kept, with buffers for a guess; a sample
+    # that keeps more makes those kernels return at once and the step runs again with the count in hand
+    if plan == "cap":
+        monkeypatch.setenv("TATAJUBA_AMD_PLAN_CAP", "500")
+    else:
+        monkeypatch.setenv("TATAJUBA_AMD_NO_PLAN", "1")
+    s = tj.synth_stream(20000, 150, 100000)
+    st, n = check_finalise([s], 10, 3, 1, 5)
+    assert st == 0 and n > 500
+    st, n = check_finalise([s[: 151 * 2000], s[151 * 2000:]], 15, 4, 0, 0)
+    assert st == 0 and n > 500
+
+
 @pytest.mark.parametrize("k,m,limit", [(10, 3, 1), (25, 4, 2), (32, 3, 1), (2, 1, 1)])
 def test_finalise_radix_fallback(monkeypatch, k, m, limit):
     # the kept set is ordered by a bin partition + rank sort; a bin fuller than the limit must switch the whole sort to
