@@ -26,7 +26,9 @@
 #define E_SUBTABLE  0x2000u
 #define E_INVALID   0x1000u
 #define E_EXTRA(e)  (((e) >> 8) & 0x0fu)
-#define E_LIT2      0x0100u             /* (literal entries) two literals: value = first | second << 8, bits = both codes */
+/* Primary literal entries of the fast loop's table (pair_literals) pack up to three literals:
+ * bits 0-3 = code bits of all of them, bits 4-5 = how many - 1, bits 8-14 = the third (ASCII only), bits 16-31 = first | second << 8. */
+#define E_LITN(e)   ((((e) >> 4) & 3u) + 1u)
 
 static const unsigned short len_base[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
 static const unsigned char  len_extra[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
@@ -136,9 +138,15 @@ pair_literals (unsigned *table, unsigned *single)
   for (i = 0; i < (1u << LIT_TABLE_BITS); i++) {
     const unsigned e1 = single[i];
     if (e1 & E_LITERAL) {
-      const unsigned l1 = e1 & 0xffu, e2 = single[i >> l1];
-      if ((e2 & E_LITERAL) && (e2 & 0xffu) + l1 <= LIT_TABLE_BITS)
-        table[i] = (((e1 >> 16) | ((e2 >> 16) << 8)) << 16) | E_LITERAL | E_LIT2 | (l1 + (e2 & 0xffu));
+      unsigned bits = e1 & 0xffu, n = 1, val = e1 >> 16, third = 0;
+      const unsigned e2 = single[i >> bits];
+      if ((e2 & E_LITERAL) && (e2 & 0xffu) + bits <= LIT_TABLE_BITS) {
+        unsigned e3;
+        val |= (e2 >> 16) << 8; bits += e2 & 0xffu; n = 2;
+        e3 = single[i >> bits];
+        if ((e3 & E_LITERAL) && (e3 & 0xffu) + bits <= LIT_TABLE_BITS && (e3 >> 16) < 128u) { third = e3 >> 16; bits += e3 & 0xffu; n = 3; }
+      }
+      table[i] = (val << 16) | E_LITERAL | (third << 8) | ((n - 1u) << 4) | bits;
     }
   }
 }
@@ -283,14 +291,14 @@ tji_inflate (tji_state *s, const unsigned char *in0, size_t in_len, size_t *in_p
           in += (63u - bitcnt) >> 3;
           bitcnt |= 56u;
           e = lt[bitbuf & ((1u << LIT_TABLE_BITS) - 1u)];
-#define PUT_LITERALS(e) do { const unsigned short v_ = (unsigned short) ((e) >> 16); memcpy (out, &v_, 2); out += 1u + (((e) >> 8) & 1u); } while (0)
-          if (e & E_LITERAL) {                          /* up to three look-ups (six literals) per refill (3 x 11 bits <= 56) */
-            DROP_BITS (e & 0xffu); PUT_LITERALS (e);
+#define PUT_LITERALS(e) do { const unsigned v_ = ((e) >> 16) | ((((e) >> 8) & 0x7fu) << 16); memcpy (out, &v_, 4); out += E_LITN (e); } while (0)
+          if (e & E_LITERAL) {                          /* up to three look-ups (nine literals) per refill (3 x 11 bits <= 56) */
+            DROP_BITS (e & 0xfu); PUT_LITERALS (e);
             e = lt[bitbuf & ((1u << LIT_TABLE_BITS) - 1u)];
             if (e & E_LITERAL) {
-              DROP_BITS (e & 0xffu); PUT_LITERALS (e);
+              DROP_BITS (e & 0xfu); PUT_LITERALS (e);
               e = lt[bitbuf & ((1u << LIT_TABLE_BITS) - 1u)];
-              if (e & E_LITERAL) { DROP_BITS (e & 0xffu); PUT_LITERALS (e); continue; }
+              if (e & E_LITERAL) { DROP_BITS (e & 0xfu); PUT_LITERALS (e); continue; }
             }
           }
           if (e & E_SUBTABLE) {

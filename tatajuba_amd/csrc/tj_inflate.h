@@ -17,7 +17,7 @@ typedef struct
   unsigned stored_left;
   unsigned pending_len;         /* rest of a match that did not fit the output buffer */
   size_t pending_dist;
-  unsigned lit_table[TJI_LIT_TABLE_CAP];   /* primary entries may hold two literals (fast loop) */
+  unsigned lit_table[TJI_LIT_TABLE_CAP];   /* primary entries may hold up to three literals (fast loop) */
   unsigned lit_single[2048];               /* the primary table with one symbol per entry (careful loop) */
   unsigned dist_table[TJI_DIST_TABLE_CAP];
 } tji_state;
