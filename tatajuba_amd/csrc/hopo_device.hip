@@ -4230,7 +4230,7 @@ extern "C" long tjamd_merge_samples (tjamd_counter *c, const void *d_records, co
 
   // bins of ~32..64 records: partition, then one wavefront per bin finds the distinct keys, their order and depths
   int nbits = 6;
-  while (nbits < BS_MAXBITS && nbits < 1 + 4 * c->k && (64l << nbits) < n) nbits++;
+  while (nbits < BS_MAXBITS && nbits < 1 + 4 * c->k && (24l << nbits) < n) nbits++;   // (the per-bin work is quadratic in the bin's size: bins of ~30 records)
   nbits = std::min (nbits, 1 + 4 * c->k);
   const int nbins = 1 << nbits;
   int rc = ensure (c->prefix, (size_t) (n_samples + 1) * 8, c->stream);
