@@ -276,10 +276,14 @@ def main():
                            variant_seed=(rank if world > 1 else 0), n_threads=max(1, 16 // max(1, min(world, 8))))
     n_bytes = host.size
     dev = torch.from_numpy(host).cuda()                 # resident in HBM before the timed region
-    stream = torch.cuda.current_stream()
-    # N > 1: two counters take turns, so that a sample's histogram stays in place while the next sample is scanned; its
-    # exchange (all-gatherv + merge, on a stream and a counter of their own) runs under that scan.
-    ctrs = [tj.Counter(k, device=local) for _ in range(2 if world > 1 else 1)]
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()                          # one stream for both counters (the default stream's handle is null, which
+                                                          # tjamd_counter_set_stream reads as "the counter's own"): samples run one after the other
+    # Two counters take turns on one stream: while the host waits for a sample's counts (tjamd_finalise_end) and, with
+    # N > 1, exchanges its histogram (all-gatherv + merge, on a stream and a counter of their own), the next sample's scan
+    # is already queued -- a step is still one whole sample, scanned and finalised, and K samples begin and end inside the
+    # timed region.
+    ctrs = [tj.Counter(k, device=local) for _ in range(2)]
     for cc in ctrs:
         cc.set_stream(stream.cuda_stream)
     c = ctrs[0]
@@ -326,28 +330,37 @@ def main():
         if worker_err:
             raise worker_err[0]
 
+    begun = None                                          # counter whose finalise has been queued but not looked at
+    times = []                                            # (scan ms, finalise ms) of every sample ended
+
+    def end_sample(cnt):
+        st = cnt.finalise_end()
+        if st != 0:
+            raise SystemExit(f"finalise status {st}")
+        times.append((cnt.last_scan_ms(), cnt.last_finalise_ms()))
+
     def step():
-        nonlocal pending, n_step, c
+        nonlocal pending, begun, n_step, c
         c = ctrs[n_step % len(ctrs)]
         n_step += 1
         exchange_join()                                   # (the exchange before last: long done)
         c.reset()
-        c.scan_device(dev.data_ptr(), n_bytes, m)       # asynchronous: the previous sample's exchange runs under it
-        if pending is not None:
-            exchange_async(pending)
-        st = c.finalise(1, args.min_coverage)
-        if st != 0:
-            raise SystemExit(f"finalise status {st}")
-        if world > 1:
-            pending = c
-        return c.last_scan_ms(), c.last_finalise_ms()
+        c.scan_device(dev.data_ptr(), n_bytes, m)       # asynchronous
+        c.finalise_begin(1, args.min_coverage)            # likewise: queued behind the scan
+        if begun is not None:                             # the sample before: its counts, then (N > 1) its exchange, under this scan
+            end_sample(begun)
+            if world > 1:
+                exchange_async(begun)
+        begun = c
 
-    def drain():                                          # the last sample's exchange
-        nonlocal pending
+    def drain():                                          # the last sample's counts and exchange
+        nonlocal pending, begun
         exchange_join()
-        if pending is not None:
-            exchange(pending)
-            pending = None
+        if begun is not None:
+            end_sample(begun)
+            if world > 1:
+                exchange(begun)
+            begun = None
 
     def fence():
         torch.cuda.synchronize()
@@ -363,14 +376,15 @@ def main():
         step()
     drain()
     fence()
+    times.clear()
     t0 = time.perf_counter()
-    scan_ms, fin_ms = [], []
     for _ in range(args.steps):
-        a, b = step()
-        scan_ms.append(a); fin_ms.append(b)
+        step()
     drain()
     fence()
     dt = time.perf_counter() - t0
+    assert len(times) == args.steps
+    scan_ms, fin_ms = [a for a, _ in times], [b for _, b in times]
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -424,7 +438,8 @@ def main():
                                f"k={k} min_tract={m} remove_biased=1 min_coverage={args.min_coverage}"
                                + (f", read length uniform in [{L}, {args.read_len_max}]" if args.read_len_max > L else "") + " -- " + workload_label(args),
                    "reads_per_gpu": args.reads, "raw_records_per_gpu": int(raw), "kept_records": int(kept),
-                   "parallelism": f"sample-per-gpu x{world}" + (", histogram exchange (all-gatherv + merge) overlapped with the next sample's scan" if world > 1 else "")},
+                   "parallelism": f"sample-per-gpu x{world}" + (", histogram exchange (all-gatherv + merge) overlapped with the next sample's scan" if world > 1 else ""),
+                   "pipelining": "two counters take turns on one stream: sample i's counts are fetched (tjamd_finalise_end) after sample i + 1 has been queued; every step is a whole sample, K begin and end inside the timed region"},
         "roofline": roof,
         "stages": {"scan": {"ms": scan_avg, "algorithmic_GBps": scan_gbs, "frac_of_hbm_peak": scan_gbs / HBM_PEAK_GBS,
                             "reads_per_s": args.reads / (scan_avg * 1e-3), "kernel": scan_kernel,

@@ -110,6 +110,12 @@ int  tjamd_upload_raw (tjamd_counter *c, const hopo_element *elems, long n);
 /* steps 1-4 + coverage on the device.  status: 0 ok, 1 no raw records, 2 nothing after filter, 3 nothing reaches
  * min_coverage (reference: src/hopo_counter.c:345-349,376-381,406-411). */
 int  tjamd_finalise (tjamd_counter *c, int remove_biased, int min_coverage, int *status);
+/* The same in two calls, for a caller with more samples than GPUs: _begin queues the whole device finalise on the counter's
+ * stream and returns; _end waits until THIS counter's counts have reached the host (an event, not the stream: the next
+ * sample's scan, queued on another counter of the same stream in between, runs on) and returns what tjamd_finalise
+ * returns.  Between the two calls the counter must not be touched. */
+int  tjamd_finalise_begin (tjamd_counter *c, int remove_biased, int min_coverage);
+int  tjamd_finalise_end (tjamd_counter *c, int *status);
 long tjamd_kept_count (tjamd_counter *c);
 int  tjamd_n_idx (tjamd_counter *c);
 int  tjamd_coverage (tjamd_counter *c);

@@ -83,7 +83,7 @@ EXPORTS = [
     "tjamd_device_count", "tjamd_last_error", "tjamd_version", "tjamd_counter_create", "tjamd_counter_destroy",
     "tjamd_counter_reset", "tjamd_counter_set_stream", "tjamd_counter_device", "tjamd_scan_device", "tjamd_scan_host",
     "tjamd_scan_host_located", "tjamd_read_file_stream_mt", "tjamd_host_alloc", "tjamd_host_free", "tjamd_device_alloc", "tjamd_device_free", "tjamd_device_download", "tjamd_sync", "tjamd_mark", "tjamd_wait_mark", "tjamd_reserve", "tjamd_raw_count",
-    "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_kept_count",
+    "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_finalise_begin", "tjamd_finalise_end", "tjamd_kept_count",
     "tjamd_n_idx", "tjamd_coverage", "tjamd_download_kept", "tjamd_download_idx", "tjamd_kept_device_ptr",
     "tjamd_merge_samples", "tjamd_gather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_scan_windows", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches",
     "tjamd_synth_stream", "tjamd_read_file_stream",
@@ -161,6 +161,8 @@ def lib():
     L.tjamd_undefined_runs.restype = C.c_long; L.tjamd_undefined_runs.argtypes = [C.c_void_p]
     L.tjamd_upload_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
     L.tjamd_finalise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.tjamd_finalise_begin.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.tjamd_finalise_end.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.tjamd_kept_count.restype = C.c_long; L.tjamd_kept_count.argtypes = [C.c_void_p]
     L.tjamd_n_idx.argtypes = [C.c_void_p]
     L.tjamd_coverage.argtypes = [C.c_void_p]
@@ -316,6 +318,15 @@ class Counter:
     def finalise(self, remove_biased, min_coverage):
         st = C.c_int(-1)
         self._chk(lib().tjamd_finalise(self._h, int(bool(remove_biased)), int(min_coverage), C.byref(st)))
+        return st.value
+
+    def finalise_begin(self, remove_biased, min_coverage):
+        """queue the device finalise and return; finalise_end() fetches the outcome (tjamd_finalise_begin / _end)"""
+        self._chk(lib().tjamd_finalise_begin(self._h, int(bool(remove_biased)), int(min_coverage)))
+
+    def finalise_end(self):
+        st = C.c_int(-1)
+        self._chk(lib().tjamd_finalise_end(self._h, C.byref(st)))
         return st.value
 
     @property

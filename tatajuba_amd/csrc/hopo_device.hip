@@ -3190,6 +3190,9 @@ struct tjamd_counter
   bool bins_zeroed = false;
   long n_kept = 0; int n_idx = 0, coverage = 0, status = -1;
   hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_f0 = nullptr, ev_f1 = nullptr;
+  hipEvent_t ev_done = nullptr;                         // tjamd_finalise_begin: the counts have reached the host
+  int fin_pending = 0;                                  // 1: begun, results not looked at yet (tjamd_finalise_end)
+  int fin_rb = 0, fin_mc = 0; bool fin_speculative = false, fin_plan_ahead = false; u64 fin_kept_cap = 0;
   hipEvent_t marks[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // tjamd_mark / tjamd_wait_mark
   unsigned mark_seq = 0;
   bool scan_timed = false, fin_timed = false;
@@ -3251,6 +3254,7 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   HIPCHK_NULL (hipMemsetAsync (c->d_lctr, 0, sizeof (DevCounters), c->stream));
   HIPCHK_NULL (hipEventCreate (&c->ev_s0)); HIPCHK_NULL (hipEventCreate (&c->ev_s1));
   HIPCHK_NULL (hipEventCreate (&c->ev_f0)); HIPCHK_NULL (hipEventCreate (&c->ev_f1));
+  HIPCHK_NULL (hipEventCreateWithFlags (&c->ev_done, hipEventDisableTiming));
   HIPCHK_NULL (hipStreamSynchronize (c->stream));
   return c;
 }
@@ -3271,6 +3275,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   if (c->ev_s1) (void) hipEventDestroy (c->ev_s1);
   if (c->ev_f0) (void) hipEventDestroy (c->ev_f0);
   if (c->ev_f1) (void) hipEventDestroy (c->ev_f1);
+  if (c->ev_done) (void) hipEventDestroy (c->ev_done);
   if (c->own_stream) (void) hipStreamDestroy (c->own_stream);
   delete c;
 }
@@ -3867,7 +3872,7 @@ static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
 // n1 > 0: the kept count, known.  n1 == 0: not fetched yet -- the kernels take their sizes from the device-side plan
 // (plan_kernel has run), the buffers hold `cap` records, and the caller looks at what came of it after the one
 // synchronisation at the end (finalise_speculative_ok).
-static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long cap = 0)
+static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long cap = 0, bool wait = true)
 {
   const bool planned = n1 == 0;
   const FinPlan *plan = planned ? &c->d_state->plan : nullptr;
@@ -3907,22 +3912,53 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long ca
   HIPCHK (hipEventRecord (c->ev_f1, c->stream));
   c->fin_timed = true;
   HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK (hipStreamSynchronize (c->stream));
+  if (wait) HIPCHK (hipStreamSynchronize (c->stream));
+  else HIPCHK (hipEventRecord (c->ev_done, c->stream));
   return TJAMD_OK;
 }
 
+// tjamd_finalise in two halves: _begin queues everything (one stream, no host synchronisation when the ordering step can be
+// planned on the device) and _end waits for the counts -- an event, not the stream: what the caller has queued behind
+// (the next sample's scan on another counter of the same stream) runs on -- and finishes the bookkeeping.
+static int finalise_impl (tjamd_counter *c, int remove_biased, int min_coverage, int *status, int phase);
+
 extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_coverage, int *status)
+{
+  int rc = finalise_impl (c, remove_biased, min_coverage, status, 0);
+  return rc;
+}
+extern "C" int tjamd_finalise_begin (tjamd_counter *c, int remove_biased, int min_coverage)
+{
+  const int rc = finalise_impl (c, remove_biased, min_coverage, nullptr, 1);
+  if (!rc && c->fin_pending == 0) c->fin_pending = 3;   // (the outcome was clear at once, e.g. no raw records: _end reports it)
+  return rc;
+}
+extern "C" int tjamd_finalise_end (tjamd_counter *c, int *status)
+{
+  if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
+  if (!c->fin_pending) return set_err (TJAMD_ERR_STATE, "tjamd_finalise_end without tjamd_finalise_begin");
+  if (c->fin_pending == 3) { c->fin_pending = 0; if (status) *status = c->status; return TJAMD_OK; }
+  return finalise_impl (c, c->fin_rb, c->fin_mc, status, 2);
+}
+
+// phase 0: all of it; 1: up to the point where the host has to know the counts; 2: from there
+static int finalise_impl (tjamd_counter *c, int remove_biased, int min_coverage, int *status, int phase)
 {
   if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
   HIPCHK (hipSetDevice (c->device));
+  bool speculative = c->fin_speculative, plan_ahead = c->fin_plan_ahead;
+  u64 kept_cap = c->fin_kept_cap;
+  int rc = TJAMD_OK;
+  if (phase == 2) goto second_half;
+  c->fin_pending = 0;
+  {
   // The raw count sizes the kept list.  A survivor stands for at least two raw records (both strands seen, or a count
   // above one), so half of the host's running upper bound of the raw count is a safe capacity: unless that is a lot of
   // memory, the aggregation is launched without first asking the device (one host round trip less) and the exact
   // counts and error flags, copied in stream order before the buckets are cleared, are looked at afterwards.
-  int rc = TJAMD_OK;
   c->n_kept = 0; c->n_idx = 0; c->coverage = 0; c->fin_timed = false;
-  const bool speculative = (c->raw_bound / 2 + 1) * 24 <= (8ull << 30);
-  u64 kept_cap = c->raw_bound / 2 + 1;
+  speculative = (c->raw_bound / 2 + 1) * 24 <= (8ull << 30);
+  kept_cap = c->raw_bound / 2 + 1;
   if (!speculative) {
     rc = sync_counters (c);
     if (rc) return rc;
@@ -3950,7 +3986,7 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   // kernels do nothing and the step is run again below with the count in hand.
   long plan_cap = (long) std::min<u64> (kept_cap, std::max<u64> (kept_cap / 8, 1u << 16));
   if (const char *pc = getenv ("TATAJUBA_AMD_PLAN_CAP")) plan_cap = std::max (1l, std::min (plan_cap, atol (pc)));     // (tests: make the second attempt happen)
-  const bool plan_ahead = speculative && getenv ("TATAJUBA_AMD_NO_PLAN") == nullptr;
+  plan_ahead = speculative && getenv ("TATAJUBA_AMD_NO_PLAN") == nullptr;
   if (plan_ahead) {
     hipLaunchKernelGGL (plan_kernel, dim3 (1), dim3 (1), 0, c->stream, (const FinCounts *) c->d_fin, c->k, plan_cap, &c->d_state->plan);
     HIPCHK (hipGetLastError ());
@@ -3958,8 +3994,16 @@ extern "C" int tjamd_finalise (tjamd_counter *c, int remove_biased, int min_cove
   rc = queue_counter_copies (c);
   if (!rc) rc = clear_buckets (c);
   if (rc) return rc;
-  if (plan_ahead) { rc = finalise_binned (c, 0, min_coverage, plan_cap); if (rc) return rc; }   // (ends with a copy of the counts and a synchronisation)
+  c->fin_rb = remove_biased; c->fin_mc = min_coverage; c->fin_speculative = speculative; c->fin_plan_ahead = plan_ahead; c->fin_kept_cap = kept_cap;
+  if (plan_ahead) { rc = finalise_binned (c, 0, min_coverage, plan_cap, phase != 1); if (rc) return rc; }   // (ends with a copy of the counts and a synchronisation, or an event)
   else HIPCHK (hipStreamSynchronize (c->stream));
+  }
+  if (phase == 1) { c->fin_pending = plan_ahead ? 1 : 2; return TJAMD_OK; }    // (2: nothing left to wait for)
+second_half:
+  if (phase == 2) {
+    if (c->fin_pending == 1) HIPCHK (hipEventSynchronize (c->ev_done));
+    c->fin_pending = 0;
+  }
   if (speculative) {
     rc = apply_counter_copies (c);
     const long n = c->n_raw_known;

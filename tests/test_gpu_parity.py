@@ -325,6 +325,50 @@ def test_streams_with_no_calls_match_the_oracle(k, m):
     assert st == 0 and kept > 100
 
 
+@pytest.mark.parametrize("mode", ["plan", "noplan", "cap"])
+def test_finalise_in_two_calls_with_two_counters_on_one_stream(monkeypatch, mode):
+    # tjamd_finalise_begin / _end: sample i's outcome is fetched after sample i + 1 has been queued on the same stream
+    if mode == "noplan":
+        monkeypatch.setenv("TATAJUBA_AMD_NO_PLAN", "1")
+    if mode == "cap":
+        monkeypatch.setenv("TATAJUBA_AMD_PLAN_CAP", "300")
+    import torch
+    streams = [tj.synth_stream(15000 + 3000 * i, 150, 80000, seed_reads=77 + i) for i in range(4)] + [np.frombuffer(b"ACGT\n", np.uint8)]
+    devs = [torch.from_numpy(s.copy()).cuda() for s in streams]
+    ctr = [tj.Counter(10), tj.Counter(10)]
+    for c in ctr:
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+    begun, got = None, []
+
+    def end(i):
+        c = ctr[i & 1]
+        st = c.finalise_end()
+        got.append((i, st, c.download_kept().tobytes() if st == 0 else b"", c.coverage if st == 0 else 0))
+
+    for i, d in enumerate(devs):
+        c = ctr[i & 1]
+        c.reset()
+        c.scan_device(d.data_ptr(), streams[i].size, 3)
+        c.finalise_begin(1, 3)
+        if begun is not None:
+            end(begun)
+        begun = i
+    end(begun)
+    assert [g[0] for g in got] == list(range(len(streams)))
+    for i, st, kept, cov in got:
+        o = orc.Oracle(10)
+        o.scan_stream(streams[i], 3)
+        o.finalise(1, 3)
+        assert st == o.c.status, i
+        if st == 0:
+            assert kept == o.elems().tobytes() and cov == o.c.coverage, i
+    assert got[-1][1] == 1                                  # (the stream without a tract: the reference's "empty sample")
+    with pytest.raises(Exception):
+        ctr[0].finalise_end()                               # nothing begun
+    for c in ctr:
+        c.close()
+
+
 @pytest.mark.parametrize("plan", ["cap", "off"])
 def test_finalise_when_more_is_kept_than_planned_for(monkeypatch, plan):
     # the ordering step is launched before the host knows how many records were kept, with buffers for a guess; a sample
