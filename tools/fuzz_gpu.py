@@ -62,7 +62,10 @@ while time.time() < t_end:
     desc = (it, k, m, rb, mc, [md for _, md in parts], [int(s.size) for s, _ in parts])
     try:
         assert c.raw_count() == o.c.n_elem, "raw count"
-        st = c.finalise(rb, mc)
+        if rng.random() < 0.4:                            # the same in two calls (tjamd_finalise_begin / _end)
+            c.finalise_begin(rb, mc); st = c.finalise_end()
+        else:
+            st = c.finalise(rb, mc)
         o.finalise(rb, mc)
         assert st == o.c.status, f"status {st} vs {o.c.status}"
         if st == 0:
