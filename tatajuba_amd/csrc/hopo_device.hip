@@ -1017,6 +1017,15 @@ struct StageSink
     L.rec[at * WS] = ((u64) hi << 32) | lo;
     L.bin[at] = (unsigned char) bucket_of_rec1 (lo, hi);
   }
+  // the same with the hash's weights in VGPRs (h0 = 0x6D2B4F0B, h1 = 0xC5A34D17, m27 = 0x07FFFFFF: see bucket_of_rec1) and no branch: a
+  // lane without a record passes at = S + lane, a spare slot
+  __device__ __forceinline__ void store1v (u32 at, u32 lo, u32 hi, u32 h0, u32 h1, u32 m27)
+  {
+    L.rec[at * WS] = ((u64) hi << 32) | lo;
+    u32 h = __builtin_amdgcn_udot4 (lo, h0, 0u, false);
+    h = __builtin_amdgcn_udot4 (hi & m27, h1, h, false);
+    L.bin[at] = (unsigned char) (h ^ (h >> 8));
+  }
   __device__ __forceinline__ void store_fields (u32 at, u64 c0, u64 c1, u32 base, u32 len10, u32 flag)
   {
     u64 w[W];
@@ -1440,6 +1449,12 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   asm ("v_mov_b32 %0, %1" : "=v"(vrs) : "s"(W == 1 ? 32 - 2 * k : 0));
   asm ("v_mov_b32 %0, 32" : "=v"(v32));
   asm ("v_mov_b32 %0, %1" : "=v"(vmp) : "s"(mprime));
+  u32 vm3, vm4, vh0, vh1, vm27;                             // "mprime >= 3", "mprime >= 4" as masks; the bucket hash's weights
+  asm ("v_mov_b32 %0, %1" : "=v"(vm3) : "s"(mprime >= 3 ? 0xFFFFFFFFu : 0u));
+  asm ("v_mov_b32 %0, %1" : "=v"(vm4) : "s"(mprime >= 4 ? 0xFFFFFFFFu : 0u));
+  asm ("v_mov_b32 %0, 0x6D2B4F0B" : "=v"(vh0));
+  asm ("v_mov_b32 %0, 0xC5A34D17" : "=v"(vh1));
+  asm ("v_mov_b32 %0, 0x07FFFFFF" : "=v"(vm27));
   const u32 own = (tid == 0 || tid >= (FK_WIN - FK_HR) / FK_UNIT) ? 0u : 0xFFFFFFFFu;   // halo lanes own no tract start
   const u32 voff16 = 16u * (u32) lane;
 
@@ -1560,11 +1575,11 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       // no run start at the next mprime - 1 positions (the usual minimum lengths without a loop: its scalar bookkeeping
       // costs more than the vector work)
       {
-        const u32 a1 = __builtin_amdgcn_alignbit (nx, S32, 1u), a2 = __builtin_amdgcn_alignbit (nx, S32, 2u);
-        if (mprime == 3) cand = cand & ~(a1 | a2);
-        else if (mprime == 2) cand = cand & ~a1;
-        else if (mprime == 4) cand = cand & ~(a1 | a2 | __builtin_amdgcn_alignbit (nx, S32, 3u));
-        else for (int j = 1; j < mprime; j++) cand &= ~__builtin_amdgcn_alignbit (nx, S32, (u32) j);
+        // (minimum lengths 2, 3, 4 through masks in VGPRs: a branch on mprime here cost a dozen scalar instructions per tile)
+        const u32 a1 = __builtin_amdgcn_alignbit (nx, S32, 1u), a2 = __builtin_amdgcn_alignbit (nx, S32, 2u), a3 = __builtin_amdgcn_alignbit (nx, S32, 3u);
+        const u32 t = __builtin_amdgcn_bitop3_b32 (a1, a2, vm3, 0xF8);      // a1 | (a2 & m3)
+        cand = __builtin_amdgcn_bitop3_b32 (cand, t, a3 & vm4, 0x10);       // cand & ~t & ~(a3 & m4)
+        if (mprime > 4) for (int j = 4; j < mprime; j++) cand &= ~__builtin_amdgcn_alignbit (nx, S32, (u32) j);
       }
       // (a run of 'N' long enough to count takes its context from the tract before it, reference src/hopo_counter.c:246-248:
       // the general kernel's business)
@@ -1693,14 +1708,18 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         // run end: first run start after s (bit 31 set: "none in 32 positions" reads as a run of 32, which is general)
         const u32 len = (u32) __builtin_ctz (__builtin_amdgcn_alignbit (s1, s0, q) | 0x80000000u) + 1u;
         const u32 need = len + vk2;                        // k letters, the tract, k letters
-        const bool general = valid && need > 32u;
+        const u32 room = v32 - need;                       // (negative: the window is too short -> `general`)
         const u32 notl = ~__builtin_amdgcn_alignbit (l1, l0, u);
-        bool ok = valid && (need <= 32u) && ((notl << ((v32 - need) & 31u)) == 0u) && (len >= vmp);
-
-        u32 glo = 0, ghi = 0;
-        if (general) {
+        // recorded: fits the window, letters all the way, long enough -- as one integer so that it costs vector
+        // instructions only (the compiler turns `a && b && c` into an exec region of six scalar instructions)
+        // (lanes past the list's end: a minimum length that nothing reaches)
+        const u32 bad = __builtin_amdgcn_bitop3_b32 (notl << (room & 31u), room >> 31, (len - (valid ? vmp : 0x1000u)) >> 31, 0xFE);
+        const bool ok = bad == 0u;
+        if (valid && (int) room < 0) {                     // (rare) the long tracts: appended on their own (before this wave's atomic is issued: its result register must not live across a call)
           const u64 rec = fast_general_tract (T, seq, n_bytes, tile * (long) FK_OWN - FK_HL, (int) s, k, mprime, (ncand_all >= 0x40000000u));
-          ok = rec != 0ull; glo = (u32) rec; ghi = (u32) (rec >> 32);
+#if !(defined(FK_EXP_STOP) && FK_EXP_STOP == 3)
+          if (rec != 0ull) sink.store1 (atomicAdd (&sink.L.n, 1u), (u32) rec, (u32) (rec >> 32));
+#endif
         }
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
         const u32 at = 0;
@@ -1729,14 +1748,14 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         const u32 c0 = rev ? rcr : l, c1 = rev ? rcl : r;
         // base << 2 | flag << 3 by table look-up on cb: A (0, fwd) 8, C (1, fwd) 12, G (-> C, rev) 20, T (-> A, rev) 16
         const u32 fld = __builtin_amdgcn_perm (0u, 0x10140C08u, cb | 0x0C0C0C00u);
-        const u32 lo = general ? glo : (c1 | (len << 24));
-        const u32 hi = general ? ghi : (c0 | (fld << 24));
+        const u32 lo = c1 | (len << 24);
+        const u32 hi = c0 | (fld << 24);
         STAMP (6);
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
         if (ok) asm volatile ("" :: "v"(lo), "v"(hi), "v"(at));
 #else
         const u32 at = lds_collect (araw) + (u32) __builtin_amdgcn_mbcnt_hi ((u32) (okm >> 32), __builtin_amdgcn_mbcnt_lo ((u32) okm, 0u));
-        if (ok) sink.store1 (at, lo, hi);
+        sink.store1v (ok ? at : (u32) sink.S + (u32) lane, lo, hi, vh0, vh1, vm27);   // (no record: a spare slot takes the write)
 #endif
         STAMP (7);
       }
