@@ -944,8 +944,8 @@ struct StageLds
   u64 rec[WORDS + SPARE * WS];                          // (BIG: slots S + lane take the writes of lanes without a record)
   u64 gbase[TJ_P];                                      // pool index of the first record of the bucket's run (BIG: byte address of sorted slot 0's place, see partition_big)
   u64 gbase2[TJ_P];                                     // pool index of the part of the run that lies in the next chunk (BIG: likewise)
-  u32 hist[TJ_P + SPARE];                               // (BIG: entries TJ_P + lane are for the lanes without a record)
-  u32 offs[TJ_P + SPARE];                               // start of the bucket's run in the sorted staging buffer
+  alignas (16) u32 hist[TJ_P + SPARE];                  // (BIG: entries TJ_P + lane are for the lanes without a record)
+  alignas (16) u32 offs[TJ_P + SPARE];                               // start of the bucket's run in the sorted staging buffer
   u32 split[TJ_P];                                      // records of the run before the chunk boundary (BIG: first sorted slot past it)
   u32 wsum[TJ_P / 64];
   u32 n;
@@ -968,6 +968,7 @@ struct StageSink
   __device__ __forceinline__ void start ()
   {
     if (threadIdx.x == 0) L.n = 0;
+    if (BIG && threadIdx.x < TJ_P) L.hist[threadIdx.x] = 0;   // (partition_big leaves the counts zeroed for the pass after it)
     bound = 0; cur_j = TJ_EMPTY; cur_chunk = TJ_NOCHUNK;
     lds_barrier ();
   }
@@ -1054,9 +1055,8 @@ struct StageSink
 #endif
     PSTAMP (9);
     const u32 n = (u32) __builtin_amdgcn_readfirstlane ((int) L.n);
-    if (tid < TJ_P + 64) L.hist[tid] = 0;
-    lds_barrier ();
-    if (tid == 0) L.n = 0;                              // (everybody has read it; the next appends come after the last barrier below)
+    // (five barriers per pass: the bucket counts are zero already -- zeroed below for the next pass, the spare ones are
+    // never looked at -- and each of the four waves that own buckets works out the whole prefix for itself)
     u64 w[R][WS];
     u32 rk[R], bb[R];
 #pragma unroll
@@ -1076,24 +1076,25 @@ struct StageSink
       }
     lds_barrier ();
     PSTAMP (10);
-    u32 cnt = 0, incl = 0, p0 = 0;
-    if (wave < TJ_P / 64) {                             // exclusive prefix of the bucket counts (waves 0..3)
-      cnt = L.hist[tid];
-      incl = wave_inclusive_scan (cnt);
-      if (lane == 63) L.wsum[wave] = incl;
-    }
-    else if (wave == TJ_P / 64) L.offs[tid] = (u32) S + (u32) lane;   // (the spare entries: rank 0 lands on staging slot S + lane)
-    lds_barrier ();
+    if (tid == 0) L.n = 0;                              // (everybody has read it; the next appends come after the last barrier below)
+    u32 cnt = 0, p0 = 0, off = 0;
     if (wave < TJ_P / 64) {
-      u32 wbase = 0;
-      for (int v = 0; v < wave; v++) wbase += L.wsum[v];
-      L.offs[tid] = wbase + incl - cnt;
+      // exclusive prefix of the 256 bucket counts, four per lane, in each of the waves 0..3 (no exchange between them);
+      // the wave writes the quarter that holds its own buckets and reads its bucket's entry back
+      const uint4 h4 = *reinterpret_cast<const uint4 *> (&L.hist[4 * lane]);
+      const u32 tot = h4.x + h4.y + h4.z + h4.w;
+      const u32 e0 = wave_inclusive_scan (tot) - tot;
+      if ((lane >> 4) == wave) *reinterpret_cast<uint4 *> (&L.offs[4 * lane]) = make_uint4 (e0, e0 + h4.x, e0 + h4.x + h4.y, e0 + h4.x + h4.y + h4.z);
+      cnt = L.hist[tid];
+      off = L.offs[tid];
       // reserve the bucket's run: the global atomic's round trip runs under the LDS permutation below (its result is
       // first looked at after that)
       if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
     }
+    else if (wave == TJ_P / 64) L.offs[tid] = (u32) S + (u32) lane;   // (the spare entries: rank 0 lands on staging slot S + lane)
     lds_barrier ();
     PSTAMP (11);
+    if (tid < TJ_P) L.hist[tid] = 0;                    // (for the next pass)
     {
       u32 dst[R];
 #pragma unroll
@@ -1113,7 +1114,6 @@ struct StageSink
       u32 thr = 0;
       if (cnt) {
         const u32 ch = (u32) TJ_CH0 << B.ch_shift;
-        const u32 off = L.offs[tid];
         bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
         const u32 j0 = chunk_of_pos (B, p0), j1 = chunk_of_pos (B, p0 + cnt - 1);
         if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (B, (u32) tid, j0, true, ctr); }
@@ -1645,6 +1645,9 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #else
     const u32 ncand_all = (u32) __builtin_amdgcn_readfirstlane ((int) T.ncand[slot]);
 #endif
+    // the records staged so far, exactly (every append of the tiles before is behind a barrier): `bound` has counted
+    // candidates, of which one in eight is not recorded -- with the true count the buffer is partitioned when it is full
+    sink.bound = (u32) __builtin_amdgcn_readfirstlane ((int) SL.n);
     u32 ncand_now = ncand_all;
     if (ncand_all >= 0x40000000u) {
       // Second chance for a tile with a byte outside the five: if all such bytes are 'N' (the no-call of every sequencer),
