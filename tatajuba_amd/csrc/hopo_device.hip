@@ -1044,7 +1044,7 @@ struct StageSink
   __device__ __forceinline__ void partition_big ()
   {
     static_assert (!BIG || BLOCK == 2 * TJ_P, "two threads per bucket");
-    constexpr int H = (R < 4) ? R : 4;                  // records per thread whose LDS loads are in flight together
+    constexpr int H = (R < 4) ? R : 4;                  // records per thread whose LDS loads are in flight together (2 and 8: the same time)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);
     lds_barrier ();                                     // every append so far is in LDS
@@ -1455,7 +1455,8 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   asm ("v_mov_b32 %0, 0x6D2B4F0B" : "=v"(vh0));
   asm ("v_mov_b32 %0, 0xC5A34D17" : "=v"(vh1));
   asm ("v_mov_b32 %0, 0x07FFFFFF" : "=v"(vm27));
-  const u32 own = (tid == 0 || tid >= (FK_WIN - FK_HR) / FK_UNIT) ? 0u : 0xFFFFFFFFu;   // halo lanes own no tract start
+  u32 own = (tid == 0 || tid >= (FK_WIN - FK_HR) / FK_UNIT) ? 0u : 0xFFFFFFFFu;   // halo lanes own no tract start
+  asm volatile ("" : "+v"(own));                        // (a VGPR, not a condition that is looked up in spilled SGPRs per tile)
   const u32 voff16 = 16u * (u32) lane;
 
   // Scalar instructions are not free on this chip (about 4.6 cycles each per SIMD, tools/ubench/valu_salu.hip), so the
@@ -1521,7 +1522,11 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   while (tile < nt_all) {
     STAMP (0);
     const u32 slot = it & 3u;
-    if (wave == 0) {
+    // (opaque: as a loop invariant the compiler keeps "wave == 0" as a 64-bit mask in a spilled pair of SGPRs and pays two
+    // v_readlane and an s_and per tile to look at it; compared afresh it is one s_cmp)
+    int wave_now = wave;
+    asm volatile ("" : "+s"(wave_now));
+    if (wave_now == 0) {
       if (tile + FK_GROUP == grp_end) { if (lane == 0) T.grp[gpar ^ 1u] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP); }
       if (lane == 0) { T.ncand[(it + 2u) & 3u] = 0; T.ncand2 = 0; }      // (zeroed two tiles ahead; the second chance's: a barrier ahead)
     }
@@ -1579,7 +1584,9 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         const u32 a1 = __builtin_amdgcn_alignbit (nx, S32, 1u), a2 = __builtin_amdgcn_alignbit (nx, S32, 2u), a3 = __builtin_amdgcn_alignbit (nx, S32, 3u);
         const u32 t = __builtin_amdgcn_bitop3_b32 (a1, a2, vm3, 0xF8);      // a1 | (a2 & m3)
         cand = __builtin_amdgcn_bitop3_b32 (cand, t, a3 & vm4, 0x10);       // cand & ~t & ~(a3 & m4)
-        if (mprime > 4) for (int j = 4; j < mprime; j++) cand &= ~__builtin_amdgcn_alignbit (nx, S32, (u32) j);
+        int mp_now = mprime;
+        asm volatile ("" : "+s"(mp_now));                 // (compared afresh: one s_cmp instead of a mask kept across the loop)
+        if (mp_now > 4) for (int j = 4; j < mp_now; j++) cand &= ~__builtin_amdgcn_alignbit (nx, S32, (u32) j);
       }
       // (a run of 'N' long enough to count takes its context from the tract before it, reference src/hopo_counter.c:246-248:
       // the general kernel's business)
