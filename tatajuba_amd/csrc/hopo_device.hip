@@ -1679,10 +1679,13 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     }
     else {
       const int ncand = (int) ncand_now;
+      // room for all of the tile's candidates (four tiles out of five): one reservation, none per round
+      const bool all_fit = sink.bound + (u32) ncand <= (u32) sink.S;
+      if (all_fit) sink.bound += (u32) ncand;
       if constexpr (W != 1) {                           // k > 12: two windows per plane (the flanks do not fit one with the tract)
         const long g0 = tile * (long) FK_OWN - FK_HL;
         for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
-          sink.reserve1 ((u32) min (ncand - cb0, FK_BLOCK));   // (may partition)
+          if (!all_fit) sink.reserve1 ((u32) min (ncand - cb0, FK_BLOCK));   // (may partition)
           if (cb0 + 64 * wave >= ncand) continue;          // (whole waves without a candidate in this round)
           const int ci = cb0 + tid;
           bool have = false;
@@ -1703,7 +1706,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         // end.  The windows depend on s alone, so all their LDS reads are in flight together: run starts from s + 1,
         // letters from s - k, and 64 bits of codes from s - k (left flank, tract, right flank).
 #if !(defined(FK_EXP_STOP) && FK_EXP_STOP == 3)
-        sink.reserve1 ((u32) min (ncand - cb0, FK_BLOCK));    // (may partition: before anything of this round is in registers)
+        if (!all_fit) sink.reserve1 ((u32) min (ncand - cb0, FK_BLOCK));    // (may partition: before anything of this round is in registers)
 #endif
         if (cb0 + 64 * wave >= ncand) continue;            // (whole waves without a candidate in this round)
         const int ci = cb0 + tid;
