@@ -1925,6 +1925,16 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       if (b0 >= n) return;
       const u32 ch = (u32) TJ_CH0 << BK.ch_shift;
       const u32 j0 = chunk_of_pos (BK, b0), bound = (j0 + 1u) * ch;
+      if (b0 + 64u * AG1_R <= min (n, bound) && j0 < AG_NCH) {      // a whole batch inside one chunk (nearly all of them):
+        const u32 c0s = (u32) __builtin_amdgcn_readfirstlane ((int) L.chunk[j0]);   // scalar address arithmetic, four plain loads
+        if (c0s != TJ_NOCHUNK) {
+          const u64 *q = src + ((u64) c0s * ch + (b0 - j0 * ch)) + (u32) lane;
+#pragma unroll
+          for (int r = 0; r < AG1_R; r++) wn[r] = q[64 * r];
+          vn = (1u << AG1_R) - 1u;
+          return;
+        }
+      }
       const u32 c0 = chunk_id (j0), c1 = (bound < n) ? chunk_id (j0 + 1u) : TJ_NOCHUNK;
       const u64 off0 = (u64) c0 * ch - (u64) j0 * ch, off1 = (u64) c1 * ch - (u64) bound;   // record index -> pool index
 #pragma unroll
@@ -1985,15 +1995,25 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
         };
         // first, every record looks at its home pair (straight-line code: the four loads are in flight together) --
         // that settles all but a few per cent of them
+        // (the loads are for every lane -- a slot without a record holds 0, whose home pair is as good as any -- and their
+        // results pass through an asm statement: left alone the compiler reads the pair's first slot, waits, looks, and
+        // reads the second slot inside a branch, record after record: eight LDS round trips in a row instead of one)
         u32 todo = 0;
+        u32 hp[AG1_R];
+        ulonglong2 hk[AG1_R];
+#pragma unroll
+        for (int r = 0; r < AG1_R; r++) {
+          hp[r] = home (w[r] & R1_KEY_MASK);
+          hk[r] = *reinterpret_cast<const ulonglong2 *> (&L.key[2 * hp[r]]);
+        }
+        asm volatile ("" : "+v"(hk[0].x), "+v"(hk[0].y), "+v"(hk[1].x), "+v"(hk[1].y), "+v"(hk[2].x), "+v"(hk[2].y), "+v"(hk[3].x), "+v"(hk[3].y));
 #pragma unroll
         for (int r = 0; r < AG1_R; r++) {
           const u64 cur = w[r];
           if (((valid >> r) & 1u) && ((cur >> R1_FLAG_SHIFT) & 3ull) != 3ull) {
             const u64 key = cur & R1_KEY_MASK;
-            const u32 pair = home (key);
-            const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *> (&L.key[2 * pair]);
-            if (kk.x == key || kk.y == key) atomicAdd (&L.cnt[4 * pair + (kk.x == key ? 0u : 2u) + ((u32) (cur >> (R1_FLAG_SHIFT + 1)) & 1u)], 1u);
+            const bool hx = hk[r].x == key, hy = hk[r].y == key;
+            if (hx | hy) atomicAdd (&L.cnt[4 * hp[r] + (hx ? 0u : 2u) + ((u32) (cur >> (R1_FLAG_SHIFT + 1)) & 1u)], 1u);
             else todo |= 1u << r;
           }
         }

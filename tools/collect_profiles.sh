@@ -7,10 +7,10 @@ TAG=${1:-r02}; shift || true
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-io-stages "$@" > $O/bench_under_rocprof.json 2> $O/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 5 --no-io-stages "$@" > $O/bench_under_rocprof.json 2> $O/kt.err
 echo "kernel trace done" > $O/progress.txt
 if [ -n "$KT_ONLY" ]; then      # kernel trace + plain bench only (the configurations other than the headline)
-  python3 $R/bench.py --no-io-stages "$@" > $O/bench_plain.json 2> $O/bench_plain.err
+  python3 $R/bench.py --steps 20 --warmup 5 --no-io-stages "$@" > $O/bench_plain.json 2> $O/bench_plain.err
   exit 0
 fi
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-io-stages "$@" > $O/fetch.out 2> $O/fetch.err
@@ -21,5 +21,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --o
 echo "sq1 done" >> $O/progress.txt
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/sq2 -o sq2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-io-stages "$@" > $O/sq2.out 2> $O/sq2.err
 echo "sq2 done" >> $O/progress.txt
-python3 $R/bench.py "$@" > $O/bench_plain.json 2> $O/bench_plain.err
+python3 $R/bench.py --steps 20 --warmup 5 "$@" > $O/bench_plain.json 2> $O/bench_plain.err
 find $O -name "*.csv" | head -20
