@@ -2902,6 +2902,27 @@ __device__ __forceinline__ void cov_add2 (u32 ka, u32 kb, int w, u64 *__restrict
   }
 }
 
+// the same in two halves, so that the caller can work while the two compare-and-swaps make their round trip to memory
+__device__ __forceinline__ void cov_add2_issue (u32 ka, u32 kb, int w, u64 *__restrict__ tab, int log2t, u64 &oa, u64 &ob)
+{
+  const u32 pa = (ka * 2654435761u) >> (32 - log2t), pb = (kb * 2654435761u) >> (32 - log2t);
+  oa = atomicCAS ((unsigned long long *) &tab[pa], 0ull, (unsigned long long) cov_word (ka, w));
+  ob = atomicCAS ((unsigned long long *) &tab[pb], 0ull, (unsigned long long) cov_word (kb, w));
+}
+__device__ __forceinline__ void cov_add2_finish (u32 ka, u32 kb, int w, u64 *__restrict__ tab, int log2t, u64 oa, u64 ob)
+{
+  const u32 tmask = (1u << log2t) - 1u;
+  const u32 pa = (ka * 2654435761u) >> (32 - log2t), pb = (kb * 2654435761u) >> (32 - log2t);
+  if (oa != 0ull) {
+    if ((u32) (oa >> 32) == ka + 1u) atomicAdd (reinterpret_cast<u32 *> (&tab[pa]), (u32) w);
+    else cov_add_from (ka, (pa + 1u) & tmask, w, tab, log2t);
+  }
+  if (ob != 0ull) {
+    if ((u32) (ob >> 32) == kb + 1u) atomicAdd (reinterpret_cast<u32 *> (&tab[pb]), (u32) w);
+    else cov_add_from (kb, (pb + 1u) & tmask, w, tab, log2t);
+  }
+}
+
 __global__ void cov_insert_kernel (const u64 *__restrict__ kept, long n1, u64 *__restrict__ tab, int log2t)
 {
   for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < 2 * n1; i += (long) gridDim.x * blockDim.x) {
@@ -2971,7 +2992,10 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
       if (t < s) {
         const u64 a0 = R[3 * t], a1 = R[3 * t + 1], am = R[3 * t + 2];
         const int w = meta_count (am);
-        cov_add2 ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t);
+        // (the coverage table's two compare-and-swaps go out first and are looked at after the ranking: their round trip
+        // to memory, a few microseconds, used to be waited for right here)
+        u64 cas_a, cas_b;
+        cov_add2_issue ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
         u32 rank = 0, ctx_before = 0, ctx_size = 0;
         int depth = 0;
         for (u32 j = 0; j < s; j++) {
@@ -2985,6 +3009,8 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
         keep = (ctx_before == 0u) && depth >= min_coverage;      // first record of its context, context deep enough
         H[t] = rank | (keep ? 0x80000000u : 0u);
         E[t] = ctx_size;
+        asm volatile ("" : "+v"(cas_a), "+v"(cas_b));      // (or the compiler tests them for zero, and waits, ahead of the loop)
+        cov_add2_finish ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
       }
       nkeep += (u32) __popcll (__ballot (keep));
     }
