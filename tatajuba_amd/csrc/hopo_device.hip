@@ -1592,6 +1592,8 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       // the general kernel's business)
       if (n_tile && (cand & N32)) T.ncand2 = 0x40000000u;
       const u32 n = (u32) __popc (cand);
+      // (tried: every lane reserves its own entries with one LDS atomic on the count word instead of the prefix sum -- 7 M
+      // fewer vector instructions, but 64 adds on one address hold the LDS pipe for as many cycles: + 17 % time)
       const u32 incl = wave_inclusive_scan (n);
       const u32 total = (u32) __builtin_amdgcn_readlane ((int) incl, 63);
       u32 wraw;
