@@ -114,7 +114,7 @@ struct FixEntry { long long pos; long long len; };
 // counts of the finalise step (device block read back by the host)
 struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow, sort_fallback, pad; };
 // The sizes the ordering kernels work with, derived on the device from the number of kept records so that the host does
-// not have to fetch that number between the aggregation and them (plan_kernel; ok = 0: nothing to do, or more records
+// not have to fetch that number between the aggregation and them (plan_tail; ok = 0: nothing to do, or more records
 // than the buffers were sized for -- every kernel then returns at once and the host takes the exact path).
 struct FinPlan { long n1; long t; int nbits, nbins, log2t, ok; u32 kept_overflow, pad; };
 
@@ -1845,9 +1845,12 @@ __global__ void init_table_kernel (u32 *table, u32 maxj, u32 *pool_next)
 // empty buckets: cursors 0, every bucket owns chunk b as its chunk 0, the rest of the table unclaimed, pool_next = TJ_P.
 // One workgroup per bucket; only the row entries the bucket can have claimed are rewritten (its records / chunk + the
 // one claimed ahead), unless the whole row is asked for.
-__global__ void clear_buckets_kernel (u32 *cursors, u64 *n_null, u32 *table, u32 maxj, int ch_shift, FinCounts *fin, u32 *bins, int nbins)
+__global__ void clear_buckets_kernel (u32 *cursors, DevCounters *ctr, u32 *table, u32 maxj, int ch_shift, FinCounts *fin, u32 *bins, int nbins)
 {
   const u32 b = blockIdx.x;
+  // the scan counters as well (all but n_undefined, which counts from reset to reset): a reset right after a finalise
+  // then needs no memset of its own
+  if (b == 0) for (u32 i = threadIdx.x; i < sizeof (DevCounters) / 4; i += blockDim.x) if (i != offsetof (DevCounters, n_undefined) / 4 && i != offsetof (DevCounters, n_undefined) / 4 + 1) reinterpret_cast<u32 *> (ctr)[i] = 0;
   if (table) {
     u32 used = maxj;
     if (ch_shift >= 0) used = min (maxj, ((cursors[b] / TJ_CH0) >> ch_shift) + 3u);
@@ -1855,7 +1858,7 @@ __global__ void clear_buckets_kernel (u32 *cursors, u64 *n_null, u32 *table, u32
   }
   if (bins) for (int i = (int) (b * blockDim.x + threadIdx.x); i < nbins; i += (int) (gridDim.x * blockDim.x)) bins[i] = 0;
   __syncthreads ();
-  if (threadIdx.x == 0) { cursors[b] = 0; if (b == 0) { cursors[TJ_P] = TJ_P; *n_null = 0; fin->n_kept = 0; fin->overflow = 0; } }
+  if (threadIdx.x == 0) { cursors[b] = 0; if (b == 0) { cursors[TJ_P] = TJ_P; fin->n_kept = 0; fin->overflow = 0; fin->pad = 0; } }
 }
 
 // chunk table with a longer row
@@ -1883,6 +1886,45 @@ __global__ void table_relayout_kernel (const u32 *__restrict__ old, u32 old_maxj
 #define AG1_R        4                   // records in flight per lane
 #define AG1_MARK     (~0ull)             // a key has bits 59-63 clear
 
+#define BS_MAXBITS   16                  // (bins of the ordering step: see bin_count_kernel)
+__host__ __device__ static inline int cov_table_bits (long n1) { int b = 10; while ((1l << b) < 4 * n1 && b < 31) b++; return b; }   // 2 n1 entries at most: half full
+__host__ __device__ static inline int bin_bits_for (long n1, int k)
+{
+  int nbits = 6;
+  while (nbits < BS_MAXBITS && nbits < 1 + 4 * k && (48l << nbits) < n1) nbits++;    // ~24..48 records per bin: most of a wavefront's lanes busy
+  return nbits < 1 + 4 * k ? nbits : 1 + 4 * k;
+}
+// The last workgroup of an aggregation to finish derives the sizes the ordering kernels work with (FinPlan) from the
+// number of kept records: what a one-thread kernel launched behind the aggregation used to do, for 5 us of stream time.
+// fin->pad counts the workgroups that are through (zero before every aggregation: here, and clear_buckets_kernel).
+// the kept list is full: said with an atomic whose return the thread waits for (see plan_tail)
+__device__ __forceinline__ void flag_kept_overflow (FinCounts *fin)
+{
+  u32 old = atomicOr (&fin->overflow, 1u);
+  asm volatile ("" :: "v"(old));
+}
+
+__device__ __forceinline__ void plan_tail (FinCounts *fin, int k, long cap, FinPlan *plan)
+{
+  if (!plan) return;
+  // (no __threadfence: at device scope it writes the XCD's L2 back, which doubled the aggregation's run time.  What the
+  // last workgroup needs from the others went through atomics that their threads waited for -- the kept count, the
+  // overflow flag -- before the barrier in front of their tick.)
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    const u32 done = atomicAdd (&fin->pad, 1u);
+    if (done == gridDim.x - 1u) {
+      const long n1 = (long) __hip_atomic_load (&fin->n_kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 ovf = __hip_atomic_load (&fin->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      plan->n1 = n1; plan->kept_overflow = ovf;
+      plan->nbits = bin_bits_for (n1, k); plan->nbins = 1 << plan->nbits;
+      plan->log2t = cov_table_bits (n1); plan->t = 1l << plan->log2t;
+      plan->ok = (n1 > 0 && n1 <= cap && !ovf) ? 1 : 0;
+      fin->pad = 0;
+    }
+  }
+}
+
 struct Agg1Lds
 {
   u64 key[AG1_S];                       // record without its strand flag (never 0: the base next to an A tract is not A)
@@ -1894,7 +1936,8 @@ struct Agg1Lds
 };
 
 __global__ __launch_bounds__ (AG_BLOCK)
-void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin,
+                        long plan_cap, FinPlan *plan)
 {
   __shared__ Agg1Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2105,7 +2148,7 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       if (metas[r]) {
         const u64 key = L.key[tid + r * AG_BLOCK];
         if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (key >> 32) & 0xFFFFFFull; q[1] = key & 0xFFFFFFull; q[2] = metas[r]; }
-        else fin->overflow = 1u;
+        else flag_kept_overflow (fin);
         at++;
       }
     __threadfence_block ();
@@ -2116,6 +2159,7 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     ASTAMP (7);
   }
   ASTAMP_FLUSH;
+  plan_tail (fin, k, plan_cap, plan);
 }
 
 // ---- W = 2 (k <= 28): word 0 of the record is never 0 and leaves bit 63 free, so it doubles as the slot's claim word:
@@ -2149,7 +2193,8 @@ struct Agg2Lds
 };
 
 __global__ __launch_bounds__ (AG_BLOCK)
-void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin,
+                        long plan_cap, FinPlan *plan)
 {
   __shared__ Agg2Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2348,7 +2393,7 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       if (metas[r]) {
         const int slot = tid + r * AG_BLOCK;
         if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (L.kk[slot].x >> 7) & m56; q[1] = L.kk[slot].y & m56; q[2] = metas[r]; }
-        else fin->overflow = 1u;
+        else flag_kept_overflow (fin);
         at++;
       }
     __threadfence_block ();
@@ -2357,6 +2402,7 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     { const u64 *t = src; src = dst; dst = (u64 *) t; }
     __syncthreads ();
   }
+  plan_tail (fin, k, plan_cap, plan);
 }
 
 // ---- W = 4 (k <= 32): the k-mers fill their 64-bit words, so the claim word is made of the small key part and a hash:
@@ -2380,7 +2426,8 @@ struct Agg4Lds
 };
 
 __global__ __launch_bounds__ (AG_BLOCK)
-void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin)
+void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin,
+                        long plan_cap, FinPlan *plan)
 {
   __shared__ Agg4Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2520,7 +2567,7 @@ void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
       if (metas[r]) {
         const int slot = tid + r * AG_BLOCK;
         if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = L.c0[slot]; q[1] = L.c1[slot]; q[2] = metas[r]; }
-        else fin->overflow = 1u;
+        else flag_kept_overflow (fin);
         at++;
       }
     __threadfence_block ();
@@ -2529,6 +2576,7 @@ void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     { const u64 *t = src; src = dst; dst = (u64 *) t; }
     __syncthreads ();
   }
+  plan_tail (fin, k, plan_cap, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2638,7 +2686,6 @@ void radix_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, lo
 // one partition by the leading bits of the key into ~n/32 bins, then every bin is rank-sorted in LDS by one wavefront.
 // Keys compare as the reference's qsort does (src/hopo_counter.c:28-38): base, ctx0, ctx1, signed length, descending.
 
-#define BS_MAXBITS   16
 #define BS_RANK_MAX  256                // records of one bin a wavefront sorts in LDS; a fuller bin -> radix sort instead
 
 __device__ __forceinline__ u32 bin_of_record (u64 c0, u64 c1, u64 meta, int k, int nbits)
@@ -3284,6 +3331,7 @@ struct tjamd_counter
   unsigned scan_seq = 0;
   size_t piece_target = TJ_SCAN_PIECE_TARGET;           // TATAJUBA_AMD_SCAN_PIECE (bytes) overrides it: tests
   bool buckets_clean = false;
+  bool ctr_clean = false;     // the scan counters are zero but for n_undefined (clear_buckets_kernel did it, no scan since)
 };
 
 static int ensure (DevBuf &b, size_t bytes, hipStream_t stream, size_t keep_bytes = 0)
@@ -3387,10 +3435,11 @@ static Buckets make_buckets (const tjamd_counter *c)
 static int clear_buckets (tjamd_counter *c)
 {
   if (!c->buckets_clean) {
-    hipLaunchKernelGGL (clear_buckets_kernel, dim3 (TJ_P), dim3 (256), 0, c->stream, c->d_cursors, &c->d_ctr->n_null,
+    hipLaunchKernelGGL (clear_buckets_kernel, dim3 (TJ_P), dim3 (256), 0, c->stream, c->d_cursors, c->d_ctr,
                         (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj, c->ch_shift, c->d_fin, (u32 *) c->bins.p, c->bins.p ? BS_MAXBINS : 0);
     HIPCHK (hipGetLastError ());
     c->buckets_clean = true;
+    c->ctr_clean = true;
     c->bins_zeroed = c->bins.p != nullptr;
   }
   c->n_raw_known = 0; c->raw_bound = 0; c->bucket_bound = 0; c->chunk_bound = TJ_P; c->ch_shift = -1;
@@ -3401,8 +3450,10 @@ extern "C" int tjamd_counter_reset (tjamd_counter *c)
 {
   if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
   HIPCHK (hipSetDevice (c->device));
-  HIPCHK (hipMemsetAsync (c->d_ctr, 0, sizeof (DevCounters), c->stream));
+  // (the memset is not needed right after a finalise whose counts the host has seen: clear_buckets_kernel zeroed the rest)
+  if (!(c->ctr_clean && c->fin_pending == 0 && c->n_undefined == 0)) HIPCHK (hipMemsetAsync (c->d_ctr, 0, sizeof (DevCounters), c->stream));
   int rc = clear_buckets (c);
+  c->ctr_clean = true;
   if (rc) return rc;
   c->n_undefined = 0;
   c->n_kept = 0; c->n_idx = 0; c->coverage = 0; c->status = -1;
@@ -3545,7 +3596,7 @@ static int ensure_buckets (tjamd_counter *c, u64 add, int grid)
   (void) grid;
   // one chunk per bucket is always claimed ahead of the cursor
   const u64 need_chunks = c->chunk_bound + (add + ch - 1) / ch + 2 * TJ_P;
-  c->buckets_clean = false;
+  c->buckets_clean = false; c->ctr_clean = false;
   const u64 need_maxj = (c->bucket_bound + add + ch - 1) / ch + 3;      // worst case: everything in one bucket
   if (need_chunks >= TJ_NOCHUNK || need_maxj >= (1ull << 31)) return set_err (TJAMD_ERR_CAPACITY, "batch too large for the chunk table");
   int rc = ensure (c->pool, (size_t) need_chunks * ch * c->W * 8, c->stream, std::min<size_t> ((size_t) (c->chunk_bound * ch * c->W * 8), c->pool.cap));
@@ -3873,23 +3924,6 @@ static unsigned grid_for (long n) { return (unsigned) std::max<long> (1, std::mi
 
 // ---- finalise steps 3-4 + coverage, two ways --------------------------------------------------------------------
 
-__host__ __device__ static inline int cov_table_bits (long n1) { int b = 10; while ((1l << b) < 4 * n1 && b < 31) b++; return b; }   // 2 n1 entries at most: half full
-__host__ __device__ static inline int bin_bits_for (long n1, int k)
-{
-  int nbits = 6;
-  while (nbits < BS_MAXBITS && nbits < 1 + 4 * k && (48l << nbits) < n1) nbits++;    // ~24..48 records per bin: most of a wavefront's lanes busy
-  return nbits < 1 + 4 * k ? nbits : 1 + 4 * k;
-}
-// the ordering step's sizes from the kept count the aggregation has just produced (the host launches the ordering kernels
-// without knowing it; `cap` = records its buffers hold)
-__global__ void plan_kernel (const FinCounts *__restrict__ fin, int k, long cap, FinPlan *__restrict__ plan)
-{
-  const long n1 = (long) fin->n_kept;
-  plan->n1 = n1; plan->kept_overflow = fin->overflow;
-  plan->nbits = bin_bits_for (n1, k); plan->nbins = 1 << plan->nbits;
-  plan->log2t = cov_table_bits (n1); plan->t = 1l << plan->log2t;
-  plan->ok = (n1 > 0 && n1 <= cap && !fin->overflow) ? 1 : 0;
-}
 
 // radix path: stable LSD sort, then heads / scans / decisions as separate kernels (any bin occupancy, any size)
 static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
@@ -3954,7 +3988,7 @@ static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
 // synchronisation at the end.  If a bin turns out too full every kernel after the bin scan does nothing, kept stays as
 // it was and FinCounts::sort_fallback comes back set.
 // n1 > 0: the kept count, known.  n1 == 0: not fetched yet -- the kernels take their sizes from the device-side plan
-// (plan_kernel has run), the buffers hold `cap` records, and the caller looks at what came of it after the one
+// (plan_tail has run), the buffers hold `cap` records, and the caller looks at what came of it after the one
 // synchronisation at the end (finalise_speculative_ok).
 static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long cap = 0, bool wait = true)
 {
@@ -4057,24 +4091,22 @@ static int finalise_impl (tjamd_counter *c, int remove_biased, int min_coverage,
   if (rc) return rc;
   HIPCHK (hipEventRecord (c->ev_f0, c->stream));
   const Buckets BK = make_buckets (c);
+  // The ordering step is launched right behind the aggregation, sized on the device (plan_tail, by the aggregation's last
+  // workgroup) for up to kept_cap / 8 records -- a sample keeps a per cent or so of its raw records -- so that the whole
+  // finalise has one host round trip; if more were kept, its kernels do nothing and the step is run again below with
+  // the count in hand.
+  long plan_cap = (long) std::min<u64> (kept_cap, std::max<u64> (kept_cap / 8, 1u << 16));
+  if (const char *pc = getenv ("TATAJUBA_AMD_PLAN_CAP")) plan_cap = std::max (1l, std::min (plan_cap, atol (pc)));     // (tests: make the second attempt happen)
+  plan_ahead = speculative && getenv ("TATAJUBA_AMD_NO_PLAN") == nullptr;
+  FinPlan *const d_plan = plan_ahead ? &c->d_state->plan : nullptr;
   switch (c->W) {
-    case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
-    case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
-    default: hipLaunchKernelGGL (aggregate4_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin); break;
+    case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin, plan_cap, d_plan); break;
+    case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin, plan_cap, d_plan); break;
+    default: hipLaunchKernelGGL (aggregate4_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin, plan_cap, d_plan); break;
   }
   HIPCHK (hipGetLastError ());
   // counters, bucket sizes and the aggregation's own counts, in one copy; then the buckets are emptied (the aggregation
   // consumed them: leftover rounds reuse their fronts) together with the counts the next aggregation adds to
-  // The ordering step is launched right behind, sized on the device (plan_kernel) for up to kept_cap / 8 records -- a sample
-  // keeps a per cent or so of its raw records -- so that the whole finalise has one host round trip; if more were kept, its
-  // kernels do nothing and the step is run again below with the count in hand.
-  long plan_cap = (long) std::min<u64> (kept_cap, std::max<u64> (kept_cap / 8, 1u << 16));
-  if (const char *pc = getenv ("TATAJUBA_AMD_PLAN_CAP")) plan_cap = std::max (1l, std::min (plan_cap, atol (pc)));     // (tests: make the second attempt happen)
-  plan_ahead = speculative && getenv ("TATAJUBA_AMD_NO_PLAN") == nullptr;
-  if (plan_ahead) {
-    hipLaunchKernelGGL (plan_kernel, dim3 (1), dim3 (1), 0, c->stream, (const FinCounts *) c->d_fin, c->k, plan_cap, &c->d_state->plan);
-    HIPCHK (hipGetLastError ());
-  }
   rc = queue_counter_copies (c);
   if (!rc) rc = clear_buckets (c);
   if (rc) return rc;
