@@ -1845,9 +1845,15 @@ __global__ void init_table_kernel (u32 *table, u32 maxj, u32 *pool_next)
 // empty buckets: cursors 0, every bucket owns chunk b as its chunk 0, the rest of the table unclaimed, pool_next = TJ_P.
 // One workgroup per bucket; only the row entries the bucket can have claimed are rewritten (its records / chunk + the
 // one claimed ahead), unless the whole row is asked for.
-__global__ void clear_buckets_kernel (u32 *cursors, DevCounters *ctr, u32 *table, u32 maxj, int ch_shift, FinCounts *fin, u32 *bins, int nbins)
+__global__ void clear_buckets_kernel (u32 *cursors, DevCounters *ctr, u32 *table, u32 maxj, int ch_shift, FinCounts *fin, u32 *bins, int nbins,
+                                      DevCounters *snap_ctr, u32 *snap_cursors)
 {
   const u32 b = blockIdx.x;
+  if (snap_ctr) {                                       // (every workgroup reads its own cursor, workgroup 0 the rest: before anything is zeroed)
+    if (threadIdx.x == 0) { snap_cursors[b] = cursors[b]; if (b == 0) snap_cursors[TJ_P] = cursors[TJ_P]; }
+    if (b == 0) for (u32 i = threadIdx.x; i < sizeof (DevCounters) / 4; i += blockDim.x) reinterpret_cast<u32 *> (snap_ctr)[i] = reinterpret_cast<const u32 *> (ctr)[i];
+    __syncthreads ();
+  }
   // the scan counters as well (all but n_undefined, which counts from reset to reset): a reset right after a finalise
   // then needs no memset of its own
   if (b == 0) for (u32 i = threadIdx.x; i < sizeof (DevCounters) / 4; i += blockDim.x) if (i != offsetof (DevCounters, n_undefined) / 4 && i != offsetof (DevCounters, n_undefined) / 4 + 1) reinterpret_cast<u32 *> (ctr)[i] = 0;
@@ -3295,7 +3301,10 @@ struct DevBuf
 
 // everything the host reads back: one device block, one pinned mirror
 // (each part on cache lines of its own: the scan's workgroups hammer ctr and cursors with atomics)
-struct DevState { alignas (256) DevCounters ctr; alignas (256) FinCounts fin; alignas (256) u32 cursors[TJ_P + 1]; alignas (256) FinPlan plan; alignas (256) u32 pad[4]; };
+// (snap_*: what ctr and cursors held when clear_buckets_kernel emptied them in a finalise -- the host reads the counts of
+// the sample from there, with the one copy at the end of the finalise, instead of copying the block before the clear)
+struct DevState { alignas (256) DevCounters ctr; alignas (256) FinCounts fin; alignas (256) u32 cursors[TJ_P + 1]; alignas (256) FinPlan plan;
+                  alignas (256) DevCounters snap_ctr; alignas (256) u32 snap_cursors[TJ_P + 1]; alignas (256) u32 pad[4]; };
 
 struct tjamd_counter
 {
@@ -3432,11 +3441,12 @@ static Buckets make_buckets (const tjamd_counter *c)
 }
 
 // forget every raw record: cursors and chunk counter to zero, chunk table to "unclaimed"
-static int clear_buckets (tjamd_counter *c)
+static int clear_buckets (tjamd_counter *c, bool snapshot = false)
 {
-  if (!c->buckets_clean) {
+  if (!c->buckets_clean || snapshot) {
     hipLaunchKernelGGL (clear_buckets_kernel, dim3 (TJ_P), dim3 (256), 0, c->stream, c->d_cursors, c->d_ctr,
-                        (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj, c->ch_shift, c->d_fin, (u32 *) c->bins.p, c->bins.p ? BS_MAXBINS : 0);
+                        (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj, c->ch_shift, c->d_fin, (u32 *) c->bins.p, c->bins.p ? BS_MAXBINS : 0,
+                        snapshot ? &c->d_state->snap_ctr : (DevCounters *) nullptr, snapshot ? c->d_state->snap_cursors : (u32 *) nullptr);
     HIPCHK (hipGetLastError ());
     c->buckets_clean = true;
     c->ctr_clean = true;
@@ -3523,24 +3533,26 @@ static int queue_counter_copies (tjamd_counter *c)
 }
 
 // the copies queued by queue_counter_copies() have arrived: errors, exact counts
-static int apply_counter_copies (tjamd_counter *c)
+static int apply_counter_copies (tjamd_counter *c, bool from_snapshot = false)
 {
   long total = 0;
   u64 mx = 0;
-  for (int b = 0; b < TJ_P; b++) { total += c->h_cursors[b]; mx = std::max<u64> (mx, c->h_cursors[b]); }
-  if (c->h_ctr->overflow == 2u)
+  struct View { const DevCounters *h_ctr; const u32 *h_cursors; } v = {c->h_ctr, c->h_cursors};
+  if (from_snapshot) { v.h_ctr = &c->h_state->snap_ctr; v.h_cursors = c->h_state->snap_cursors; }
+  for (int b = 0; b < TJ_P; b++) { total += v.h_cursors[b]; mx = std::max<u64> (mx, v.h_cursors[b]); }
+  if (v.h_ctr->overflow == 2u)
     return set_err (TJAMD_ERR_HIP, "a chunk of raw record storage was claimed but its id was never published (waited %u polls): "
                     "the claiming workgroup did not make progress -- please report; scanning again usually succeeds", (unsigned) TJ_SPIN_MAX);
-  if (c->h_ctr->overflow)
+  if (v.h_ctr->overflow)
     return set_err (TJAMD_ERR_CAPACITY, "raw record storage exhausted (%u of %u chunks handed out, fullest bucket %llu records): "
-                    "raise TATAJUBA_AMD_BUCKET_SLACK (now %.1f) and scan again", c->h_cursors[TJ_P], c->pool_chunks, (unsigned long long) mx, c->slack);
-  if (c->h_ctr->fix_overflow) return set_err (TJAMD_ERR_CAPACITY, "too many non-ACGTU tract candidates in one batch (%llu)",
-                                             (unsigned long long) std::max (c->h_ctr->lc[0].n_fix, c->h_ctr->lc[1].n_fix));
-  c->n_raw_known = total - (long) c->h_ctr->n_null;
+                    "raise TATAJUBA_AMD_BUCKET_SLACK (now %.1f) and scan again", v.h_cursors[TJ_P], c->pool_chunks, (unsigned long long) mx, c->slack);
+  if (v.h_ctr->fix_overflow) return set_err (TJAMD_ERR_CAPACITY, "too many non-ACGTU tract candidates in one batch (%llu)",
+                                             (unsigned long long) std::max (v.h_ctr->lc[0].n_fix, v.h_ctr->lc[1].n_fix));
+  c->n_raw_known = total - (long) v.h_ctr->n_null;
   c->raw_bound = (u64) c->n_raw_known;
   c->bucket_bound = mx;
-  c->chunk_bound = c->h_cursors[TJ_P];
-  c->n_undefined = (long) c->h_ctr->n_undefined;
+  c->chunk_bound = v.h_cursors[TJ_P];
+  c->n_undefined = (long) v.h_ctr->n_undefined;
   return TJAMD_OK;
 }
 
@@ -4029,7 +4041,8 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long ca
   HIPCHK (hipGetLastError ());
   HIPCHK (hipEventRecord (c->ev_f1, c->stream));
   c->fin_timed = true;
-  HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
+  if (planned) HIPCHK (hipMemcpyAsync (c->h_state, c->d_state, sizeof (DevState), hipMemcpyDeviceToHost, c->stream));   // (counts of the sample, plan, results: one copy)
+  else HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
   if (wait) HIPCHK (hipStreamSynchronize (c->stream));
   else HIPCHK (hipEventRecord (c->ev_done, c->stream));
   return TJAMD_OK;
@@ -4107,8 +4120,9 @@ static int finalise_impl (tjamd_counter *c, int remove_biased, int min_coverage,
   HIPCHK (hipGetLastError ());
   // counters, bucket sizes and the aggregation's own counts, in one copy; then the buckets are emptied (the aggregation
   // consumed them: leftover rounds reuse their fronts) together with the counts the next aggregation adds to
-  rc = queue_counter_copies (c);
-  if (!rc) rc = clear_buckets (c);
+  // (with the ordering step planned ahead the copy waits until that has run: clear_buckets_kernel keeps what it zeroes)
+  rc = plan_ahead ? TJAMD_OK : queue_counter_copies (c);
+  if (!rc) rc = clear_buckets (c, plan_ahead);
   if (rc) return rc;
   c->fin_rb = remove_biased; c->fin_mc = min_coverage; c->fin_speculative = speculative; c->fin_plan_ahead = plan_ahead; c->fin_kept_cap = kept_cap;
   if (plan_ahead) { rc = finalise_binned (c, 0, min_coverage, plan_cap, phase != 1); if (rc) return rc; }   // (ends with a copy of the counts and a synchronisation, or an event)
@@ -4121,7 +4135,7 @@ second_half:
     c->fin_pending = 0;
   }
   if (speculative) {
-    rc = apply_counter_copies (c);
+    rc = apply_counter_copies (c, plan_ahead);
     const long n = c->n_raw_known;
     c->n_raw_known = 0; c->raw_bound = 0; c->bucket_bound = 0; c->chunk_bound = TJ_P;      // (the buckets are empty again)
     if (rc) return rc;
