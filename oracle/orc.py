@@ -42,8 +42,8 @@ class _OrcCounter(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "liborc.so")
-    src = os.path.join(_HERE, "hopo_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("hopo_oracle.c", "context_oracle.c", "hopo_oracle.h", "Makefile")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liborc.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -67,6 +67,12 @@ def lib():
         L.orc_group_contexts.restype = C.c_long
         L.orc_group_contexts.argtypes = [C.c_void_p, C.c_long, C.c_int] + [C.c_void_p] * 6
         L.orc_tract_ids.restype = C.c_long; L.orc_tract_ids.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        L.orc_name_from_contexts.restype = C.c_void_p; L.orc_name_from_contexts.argtypes = [U64P, C.c_int, C.c_int, C.c_int]
+        L.orc_levenshtein.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.orc_genomic_context_list.restype = C.c_long
+        L.orc_genomic_context_list.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+        L.orc_merge_samples.restype = C.c_long
+        L.orc_merge_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_parse_file_to_stream.restype = C.c_void_p
         L.orc_parse_file_to_stream.argtypes = [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
         _LIB = L
@@ -169,3 +175,44 @@ def tract_ids(rec3):
     out = np.zeros(max(n, 1), np.int32)
     nid = lib().orc_tract_ids(r.ctypes.data, n, out.ctypes.data)
     return out[:n], nid
+
+
+ORC_GROUP_DTYPE = np.dtype([("first", "<i4"), ("n_elem", "<i4"), ("n_context", "<i4"), ("mode", "<i4"), ("indel", "<i4"), ("n_len", "<i4"),
+                            ("modal_len", "<i4"), ("modal_freq", "<i4"), ("mode_context_id", "<i4"), ("mode_context_count", "<i4"),
+                            ("mode_context_length", "<i4"), ("_pad", "<i4"), ("integral", "<i8")])
+assert ORC_GROUP_DTYPE.itemsize == 56
+
+
+def levenshtein(a, b, cost_sub=1, cost_indel=1):
+    """UNPINNED restatement of biomcmc_levenshtein_distance (see context_oracle.c)"""
+    a, b = (x.encode("latin-1") if isinstance(x, str) else x for x in (a, b))
+    return lib().orc_levenshtein(a, len(a), b, len(b), cost_sub, cost_indel)
+
+
+def genomic_context_list(elems, kmer_size, max_distance_per_flank, levenshtein_distance, min_tract_size):
+    """oracle restatement of new_genomic_context_list (grouping with the indel retry + length histograms, see
+    context_oracle.c).  Returns dict: group_of, join_type (per element), groups (ORC_GROUP_DTYPE), hist_len, hist_freq
+    (per-element arrays: group g's histogram at [first, first + n_len)), contexts (uint64 [n, 2]: g's list at first ...)"""
+    e = np.ascontiguousarray(elems)
+    n = len(e)
+    m = max(n, 1)
+    gof, jt, hl, hf = (np.zeros(m, np.int32) for _ in range(4))
+    g = np.zeros(m, ORC_GROUP_DTYPE)
+    ctx = np.zeros((m, 2), np.uint64)
+    ng = lib().orc_genomic_context_list(e.ctypes.data, n, kmer_size, max_distance_per_flank, levenshtein_distance, min_tract_size,
+                                        gof.ctypes.data, jt.ctypes.data, g.ctypes.data, hl.ctypes.data, hf.ctypes.data, ctx.ctypes.data)
+    return {"group_of": gof[:n], "join_type": jt[:n], "groups": g[:ng], "hist_len": hl[:n], "hist_freq": hf[:n], "contexts": ctx[:n]}
+
+
+def merge_samples(rec3, counts):
+    """oracle restatement of the cross-sample merge order (src/genome_set.c:250-289) on context keys.  rec3: uint64 [n, 3]
+    (the samples' kept tjamd_records back to back), counts: records per sample.  Returns (cat_sample, cat_index,
+    keys uint64 [n_union, 3], per-sample counts int32 [n_union, n_samples])."""
+    r = np.ascontiguousarray(rec3, dtype=np.uint64).reshape(-1, 3)
+    n, ns = len(r), len(counts)
+    cnt = (C.c_long * ns)(*[int(x) for x in counts])
+    cs, ci = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    keys = np.zeros((max(n, 1), 3), np.uint64)
+    mat = np.zeros((max(n, 1), ns), np.int32)
+    nu = lib().orc_merge_samples(r.ctypes.data, cnt, ns, cs.ctypes.data, ci.ctypes.data, keys.ctypes.data, mat.ctypes.data)
+    return cs[:n], ci[:n], keys[:nu], mat[:nu]

@@ -959,6 +959,12 @@ struct StageSink
   static constexpr int S = StageLds<W, BIG>::S;
   static constexpr int WS = StageLds<W, BIG>::WS;
   static constexpr int R = (S + BLOCK - 1) / BLOCK;     // staged records per thread in a partition pass
+  // The fast kernel's one-word sink partitions exactly PS records at a time whenever it holds that many (the usual case:
+  // a pass is asked for when the next round of BLOCK candidates might not fit, i.e. with S - BLOCK .. S records staged):
+  // every round of the pass is full, so it is compiled without the "does this round hold a record" scalar tests (some 130
+  // scalar instructions per wave and pass) and without the per-slot "is there a record" selects; what is staged beyond PS
+  // (fewer than BLOCK records) moves to the front for the next pass.  PS = 0: no such pass.
+  static constexpr int PS = (BIG && W == 1 && S > BLOCK && (S - BLOCK) % BLOCK == 0) ? S - BLOCK : 0;
   StageLds<W, BIG> &L;
   Buckets B; DevCounters *ctr; int k;
   u32 bound;                                            // upper bound of the records staged (workgroup-uniform)
@@ -978,7 +984,7 @@ struct StageSink
   // `round_max`: workgroup-uniform upper bound of the lanes that bring a record in this call
   __device__ __forceinline__ void put (bool have, u64 c0, u64 c1, u32 base, u32 len10, u32 flag, u64 pos, u32 round_max)
   {
-    if (bound + round_max > (u32) S) { partition (); bound = 0; }
+    if (bound + round_max > (u32) S) bound = partition ();
     bound += round_max;
     if (have) {
       // (a uniform-address atomic under a divergent condition: the compiler's atomic optimiser makes it one LDS atomic
@@ -995,7 +1001,7 @@ struct StageSink
   // a one-word record already packed (scan_fast_kernel); same contract as put
   __device__ __forceinline__ void put1 (bool have, u32 lo, u32 hi, u32 round_max)
   {
-    if (bound + round_max > (u32) S) { partition (); bound = 0; }
+    if (bound + round_max > (u32) S) bound = partition ();
     bound += round_max;
     if (have) {
       const u32 at = atomicAdd (&L.n, 1u);
@@ -1009,7 +1015,7 @@ struct StageSink
   // at = lds_collect (raw) + rank in the wave; if (have) store1 (at, lo, hi);
   __device__ __forceinline__ void reserve1 (u32 round_max)
   {
-    if (bound + round_max > (u32) S) { partition (); bound = 0; }
+    if (bound + round_max > (u32) S) bound = partition ();
     bound += round_max;
   }
   __device__ __forceinline__ u32 count_addr () const { return (u32) (size_t) (lptr_t) &L.n; }
@@ -1041,42 +1047,63 @@ struct StageSink
   // store to the pool is masked; rounds r with r * BLOCK >= n hold no record at all and are skipped by a scalar branch.
   // (A branch per record costs three scalar instructions and an exec round trip, and scalar instructions are as dear as
   // vector ones on this chip.)
-  __device__ __forceinline__ void partition_big ()
+  // returns the records that stay staged (workgroup-uniform)
+  __device__ __forceinline__ u32 partition_big (const bool final_pass = false)
   {
-    static_assert (!BIG || BLOCK == 2 * TJ_P, "two threads per bucket");
-    constexpr int H = (R < 4) ? R : 4;                  // records per thread whose LDS loads are in flight together (2 and 8: the same time)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);
     lds_barrier ();                                     // every append so far is in LDS
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 1            // experiment builds only: records dropped
-    if (tid == 0) L.n = 0;
+    if (threadIdx.x == 0) L.n = 0;
     lds_barrier ();
-    return;
+    return 0u;
 #endif
     PSTAMP (9);
     const u32 n = (u32) __builtin_amdgcn_readfirstlane ((int) L.n);
+    if constexpr (PS > 0) {
+      // (fewer than PS records: the caller's bound had counted candidates that were not recorded -- the round it asked
+      // room for fits, n + BLOCK <= S, and the exact count is what it gets back; only finish () empties a partial buffer,
+      // so that the loop holds one copy of the pass, the one without tests)
+      if (n >= (u32) PS || final_pass) return final_pass ? partition_pass<false> (n) : partition_pass<true> (n);
+      return n;
+    }
+    else return partition_pass<false> (n);
+  }
+
+  // FULL: the pass takes exactly the first PS staged records (all RR rounds are full); otherwise all n of them
+  template <bool FULL>
+  __device__ __forceinline__ u32 partition_pass (const u32 n)
+  {
+    static_assert (!BIG || BLOCK == 2 * TJ_P, "two threads per bucket");
+    constexpr int RR = FULL ? PS / BLOCK : R;
+    constexpr int H = (RR < 4) ? RR : 4;                // records per thread whose LDS loads are in flight together (2 and 8: the same time)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);
     // (five barriers per pass: the bucket counts are zero already -- zeroed below for the next pass, the spare ones are
     // never looked at -- and each of the four waves that own buckets works out the whole prefix for itself)
-    u64 w[R][WS];
-    u32 rk[R], bb[R];
+    u64 w[RR][WS], wrem[WS];
+    u32 rk[RR], bb[RR], brem = 0;
 #pragma unroll
-    for (int r = 0; r < R; r++)                         // my records ...
-      if ((u32) r * BLOCK < n) {
+    for (int r = 0; r < RR; r++)                        // my records ...
+      if (FULL || (u32) r * BLOCK < n) {
         const u32 i = (u32) tid + (u32) r * BLOCK;
         bb[r] = L.bin[i];
 #pragma unroll
         for (int j = 0; j < WS; j++) w[r][j] = L.rec[i * WS + j];
       }
+    if constexpr (FULL) {                               // (what is staged beyond PS: kept in registers until the buffer is free)
+      brem = L.bin[(u32) PS + (u32) tid];
 #pragma unroll
-    for (int r = 0; r < R; r++)                         // ... and their rank inside their bucket
-      if ((u32) r * BLOCK < n) {
+      for (int j = 0; j < WS; j++) wrem[j] = L.rec[((u32) PS + (u32) tid) * WS + j];
+    }
+#pragma unroll
+    for (int r = 0; r < RR; r++)                        // ... and their rank inside their bucket
+      if (FULL || (u32) r * BLOCK < n) {
         const u32 i = (u32) tid + (u32) r * BLOCK;
-        bb[r] = (i < n) ? bb[r] : (u32) (TJ_P + lane);
+        if constexpr (!FULL) bb[r] = (i < n) ? bb[r] : (u32) (TJ_P + lane);
         rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
       }
     lds_barrier ();
     PSTAMP (10);
-    if (tid == 0) L.n = 0;                              // (everybody has read it; the next appends come after the last barrier below)
+    if (tid == 0) L.n = FULL ? n - (u32) PS : 0u;       // (everybody has read it; the next appends come after the last barrier below)
     u32 cnt = 0, p0 = 0, off = 0;
     if (wave < TJ_P / 64) {
       // exclusive prefix of the 256 bucket counts, four per lane, in each of the waves 0..3 (no exchange between them);
@@ -1091,18 +1118,18 @@ struct StageSink
       // first looked at after that)
       if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
     }
-    else if (wave == TJ_P / 64) L.offs[tid] = (u32) S + (u32) lane;   // (the spare entries: rank 0 lands on staging slot S + lane)
+    else if (!FULL && wave == TJ_P / 64) L.offs[tid] = (u32) S + (u32) lane;   // (the spare entries: rank 0 lands on staging slot S + lane)
     lds_barrier ();
     PSTAMP (11);
     if (tid < TJ_P) L.hist[tid] = 0;                    // (for the next pass)
     {
-      u32 dst[R];
+      u32 dst[RR];
 #pragma unroll
-      for (int r = 0; r < R; r++) if ((u32) r * BLOCK < n) dst[r] = L.offs[bb[r]];
+      for (int r = 0; r < RR; r++) if (FULL || (u32) r * BLOCK < n) dst[r] = L.offs[bb[r]];
 #pragma unroll
-      for (int r = 0; r < R; r++)                       // in-place permutation into bucket order (records are in registers)
-        if ((u32) r * BLOCK < n) {
-          const u32 d = dst[r] + ((bb[r] < (u32) TJ_P) ? rk[r] : 0u);
+      for (int r = 0; r < RR; r++)                      // in-place permutation into bucket order (records are in registers)
+        if (FULL || (u32) r * BLOCK < n) {
+          const u32 d = FULL ? dst[r] + rk[r] : dst[r] + ((bb[r] < (u32) TJ_P) ? rk[r] : 0u);
 #pragma unroll
           for (int j = 0; j < WS; j++) L.rec[d * WS + j] = w[r][j];
           L.bin[d] = (unsigned char) bb[r];
@@ -1131,14 +1158,14 @@ struct StageSink
     lds_barrier ();
     PSTAMP (14);
 #pragma unroll
-    for (int r0 = 0; r0 < R; r0 += H)
-      if ((u32) r0 * BLOCK < n) {
+    for (int r0 = 0; r0 < RR; r0 += H)
+      if (FULL || (u32) r0 * BLOCK < n) {
         u32 cb[H], cthr[H];
         u64 ca1[H], ca2[H], cw[H][WS];
 #pragma unroll
-        for (int h = 0; h < H; h++) if (r0 + h < R) cb[h] = L.bin[(u32) tid + (u32) (r0 + h) * BLOCK];
+        for (int h = 0; h < H; h++) if (r0 + h < RR) cb[h] = L.bin[(u32) tid + (u32) (r0 + h) * BLOCK];
 #pragma unroll
-        for (int h = 0; h < H; h++) if (r0 + h < R) {
+        for (int h = 0; h < H; h++) if (r0 + h < RR) {
           const u32 i = (u32) tid + (u32) (r0 + h) * BLOCK;
           const u32 b = cb[h] & (u32) (TJ_P - 1);       // (slots past n hold stale bytes: any bucket will do, the store is masked)
           cthr[h] = L.split[b]; ca1[h] = L.gbase[b]; ca2[h] = L.gbase2[b];
@@ -1146,13 +1173,13 @@ struct StageSink
           for (int j = 0; j < WS; j++) cw[h][j] = L.rec[i * WS + j];
         }
 #pragma unroll
-        for (int h = 0; h < H; h++) if (r0 + h < R) {   // sorted slot i -> its place in the bucket's run (coalesced per run)
+        for (int h = 0; h < H; h++) if (r0 + h < RR) {  // sorted slot i -> its place in the bucket's run (coalesced per run)
           const u32 i = (u32) tid + (u32) (r0 + h) * BLOCK;
           const u64 a = (i < cthr[h]) ? ca1[h] : ca2[h];
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 3
           if (a == 0x123456789ull)
 #else
-          if (i < n && a != 0ull)
+          if ((FULL || i < n) && a != 0ull)
 #endif
           {
             u64 *q = reinterpret_cast<u64 *> (a + (8ull * W) * i);
@@ -1164,11 +1191,22 @@ struct StageSink
       }
     lds_barrier ();                                     // the staging buffer is free again
     PSTAMP (15);
+    if constexpr (FULL) {
+      // what was staged beyond PS opens the next pass's buffer (the appends that follow go to slots n - PS and up: no
+      // slot is written from both sides)
+      if ((u32) PS + (u32) tid < n) {
+#pragma unroll
+        for (int j = 0; j < WS; j++) L.rec[(u32) tid * WS + j] = wrem[j];
+        L.bin[tid] = (unsigned char) brem;
+      }
+      return n - (u32) PS;
+    }
+    return 0u;
   }
 
-  __device__ __forceinline__ void partition ()
+  __device__ __forceinline__ u32 partition (const bool final_pass = false)
   {
-    if constexpr (BIG) { partition_big (); return; }
+    if constexpr (BIG) return partition_big (final_pass);
     // (scan_bins_kernel, 80 registers: one record at a time)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     lds_barrier ();                                     // every append so far is in LDS
@@ -1246,9 +1284,10 @@ struct StageSink
       }
     }
     lds_barrier ();                                     // the staging buffer is free again
+    return 0u;
   }
 
-  __device__ __forceinline__ void finish () { partition (); }
+  __device__ __forceinline__ void finish () { partition (true); }
 };
 
 #define TJ_SB_BLOCK 512
