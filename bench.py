@@ -17,6 +17,7 @@ headline, and the default); `config.workload` names what was really run.
 Prints ONE JSON line on rank 0.  The CPU oracle is used only for the cpu_baseline leg (never in the timed GPU path).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import socket
@@ -241,6 +242,10 @@ def main():
             if kk != "label":
                 setattr(args, kk, vv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # (under a profiler the preloaded library has already initialised the GPU in this process: starting the ranks from
+        # here would be a launcher hop the pool forbids -- profile one rank with RANK / WORLD_SIZE / LOCAL_RANK set instead)
+        if any(v in os.environ for v in ("ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            raise SystemExit("bench.py --gpus N > 1 does not start its own ranks under rocprofv3: profile one rank (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT set)")
         raise SystemExit(self_launch(args))
     if args.rehearse:
         return rehearse(args)
@@ -297,13 +302,36 @@ def main():
     pending = None                                        # counter whose histogram has not been exchanged yet
     n_step = 0
 
+    # The exchange is the C library's (tjamd_allgather_histograms: ncclAllGather over RCCL, on the side stream) whenever the
+    # ranks have a GPU each; the gloo rehearsal on a one-GPU box keeps the torch.distributed plumbing of tatajuba_amd/dist.py.
+    comm = None
+    union_buf = {"keys": None, "mat": None, "cap": 0}
+    if world > 1 and backend == "nccl":
+        ident = [tj.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)          # (the id travels over the job's own rendezvous)
+        comm = tj.Comm(merger, ident[0], rank, world)
+        comm.set_stream(side.cuda_stream)
+
     def exchange(cnt):
         nonlocal gathered
-        from tatajuba_amd.dist import all_gather_histograms, merge_histograms_device
         torch.cuda.set_device(local)                      # (device and stream are per thread)
+        if comm is not None:
+            ptr, cnts, tot = comm.allgather(cnt)          # all-gatherv of the per-sample histograms: one ncclAllGather per exchange
+            if tot > union_buf["cap"]:                    # (output buffers of the merge: grown, never per step)
+                union_buf["cap"] = int(tot * 1.5) + 1024
+                with torch.cuda.stream(side):
+                    union_buf["keys"] = torch.empty(union_buf["cap"] * 24, dtype=torch.uint8, device="cuda")
+                    union_buf["mat"] = torch.empty((union_buf["cap"], world), dtype=torch.int32, device="cuda")
+            nu = tj.lib().tjamd_merge_samples(merger._h, ptr, cnts, world, C.c_void_p(union_buf["keys"].data_ptr()),
+                                              C.c_void_p(union_buf["mat"].data_ptr()), tot)   # every rank holds the union (reference: genome_set.c:250-289)
+            if nu < 0:
+                raise RuntimeError(tj.lib().tjamd_last_error().decode())
+            gathered = (union_buf["keys"][: nu * 24], union_buf["mat"][:nu])
+            return
+        from tatajuba_amd.dist import all_gather_histograms, merge_histograms_device
         with torch.cuda.stream(side):
-            rec, cnts = all_gather_histograms(cnt, dist)    # RCCL all-gatherv of the per-sample histograms
-            gathered = merge_histograms_device(merger, rec, cnts)   # every rank holds the union (reference: genome_set.c:250-289)
+            rec, cnts = all_gather_histograms(cnt, dist)
+            gathered = merge_histograms_device(merger, rec, cnts)
 
     # The exchange has host synchronisations of its own (sizes, union size): it runs in a helper thread so that the main
     # thread can go on to the finalise of the sample being scanned.  Only that thread issues collectives while the loop

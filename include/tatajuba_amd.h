@@ -40,7 +40,8 @@ enum { TJAMD_OK = 0, TJAMD_ERR_NO_DEVICE = 1, TJAMD_ERR_HIP = 2, TJAMD_ERR_ARG =
 
 int  tjamd_device_count (void);                   /* number of visible HIP devices (0 => every entry below fails loudly) */
 const char *tjamd_last_error (void);              /* thread-local message of the last failure */
-const char *tjamd_version (void);
+const char *tjamd_version (void);        /* name, version and the hash of the sources the library was built from */
+const char *tjamd_source_hash (void);    /* that hash alone (tatajuba_amd/build.py computes the same over the tree) */
 
 tjamd_counter *tjamd_counter_create (int device, int kmer_size);   /* NULL on failure (see tjamd_last_error) */
 void tjamd_counter_destroy (tjamd_counter *c);
@@ -125,7 +126,8 @@ const void *tjamd_kept_device_ptr (tjamd_counter *c);   /* tjamd_record[kept_cou
 
 /* cross-sample merge on one device (reference precursor of src/genome_set.c:250-289, keyed by context instead of
  * BWA location): concatenation of n_samples kept arrays (d_records, counts[]) -> sorted union with per-sample counts.
- * out_keys: tjamd_record[n_union] (count field = total), out_counts: int32[n_union * n_samples].  Returns n_union. */
+ * out_keys: tjamd_record[n_union] (count field = total over the samples, canon_flag = OR of the samples' flags),
+ * out_counts: int32[n_union * n_samples].  Returns n_union. */
 long tjamd_merge_samples (tjamd_counter *c, const void *d_records, const long *counts, int n_samples,
                           void *d_out_keys, void *d_out_counts, long capacity);
 
@@ -134,6 +136,32 @@ long tjamd_merge_samples (tjamd_counter *c, const void *d_records, const long *c
  * `samples`, whatever devices they live on, copied back to back into a buffer on dst's device (peer copies over xGMI).
  * counts[i] = records of sample i, *d_records = the buffer (owned by dst until its next gather).  Returns the total. */
 long tjamd_gather_histograms (tjamd_counter *dst, tjamd_counter *const *samples, int n_samples, const void **d_records, long *counts);
+
+/* which device pairs the gathers of this process have used, and how: "dst<-src:direct" (peer access, xGMI) or
+ * "dst<-src:staged" (peer access refused: the runtime copies through host memory).  Returns the number of staged pairs. */
+int tjamd_peer_access_report (char *out, int capacity);
+
+/* The same exchange between PROCESSES, one per GPU (north_star: "an RCCL all-gatherv over xGMI of the per-sample
+ * histograms"; reference attach point src/genome_set.c:195-229, where the samples are threads and nothing moves): every
+ * rank contributes its finalised counter's kept records and receives every rank's, in rank order, back to back in a device
+ * buffer the communicator owns (valid until its next exchange), ready for tjamd_merge_samples.  Two calls set it up:
+ *   rank 0:      tjamd_comm_unique_id (id)            -> TJAMD_COMM_ID_BYTES bytes to hand to the other ranks (MPI_Bcast, a file, ...)
+ *   every rank:  tjamd_comm_create (c, id, rank, world)   collective; the communicator is bound to c's device
+ * and tjamd_allgather_histograms (c, comm, &d_records, counts[world]) is the exchange: ncclAllGather on c's stream, one
+ * block per rank (its count, then its records), block size agreed from the counts of the exchange before; returns the total
+ * number of records, counts[r] = records of rank r.  Collective: every rank calls it, in the same order. */
+#define TJAMD_COMM_ID_BYTES 128
+typedef struct tjamd_comm tjamd_comm;
+int  tjamd_comm_unique_id (void *id_bytes);
+tjamd_comm *tjamd_comm_create (tjamd_counter *c, const void *id_bytes, int rank, int world);
+void tjamd_comm_destroy (tjamd_comm *comm);
+/* run the exchanges on this HIP stream instead of the exchanged counter's (null: back to the counter's): a finalised
+ * sample's exchange then runs beside the next sample's scan.  The caller must have seen the counter's finalise end. */
+int  tjamd_comm_set_stream (tjamd_comm *comm, void *hip_stream);
+int  tjamd_comm_rank (const tjamd_comm *comm);
+int  tjamd_comm_world (const tjamd_comm *comm);
+long tjamd_comm_collectives (const tjamd_comm *comm);    /* RCCL calls issued so far (diagnostic: one per exchange once the block size has settled) */
+long tjamd_allgather_histograms (tjamd_counter *c, tjamd_comm *comm, const void **d_records, long *counts);
 
 /* tract ids on a merged union (reference: src/genome_set.c:207-221, context-keyed: the id goes up wherever
  * (base, ctx0, ctx1) changes between neighbours of d_keys = tjamd_record[n] in the reference's descending order).
@@ -146,6 +174,27 @@ long tjamd_tract_ids (tjamd_counter *c, const void *d_keys, long n, int *d_tract
  * first element, elements, distinct contexts, element with the modal count, summed count.  Returns the number of groups. */
 typedef struct { int first, n_elem, n_context, mode; long long integral; } tjamd_group;
 long tjamd_group_contexts (tjamd_counter *c, int max_distance_per_flank, int *group_of, tjamd_group *groups, long capacity);
+
+/* The whole grouping step (reference: new_genomic_context_list, src/context_histogram.c:245-270 and :278-286): the flank
+ * distance test as above, then, for an element of the histogram's base that fails it, the retry with an edit distance
+ * between the "left.B.right" names of the histogram's modal context and of the element (:19-23,255-261: joins if it is below
+ * levenshtein_distance and marks the histogram `indel`), then every histogram's tract lengths weighted by count, highest
+ * count first (:282 new_empfreq_from_int_weighted; modal_len / modal_freq = its first entry).  The edit distance stands
+ * for biomcmc_levenshtein_distance (.., 1, 1, true) of biomcmc-lib, absent from the reference tree: unit-cost global edit
+ * distance; likewise the order among equal counts (larger length first).
+ *   group_of   int32[kept_count]   histogram of each element (host, may be NULL)
+ *   join_type  int32[kept_count]   0 = the element opened its histogram, 1 = joined within the flank distance, 2 = by the retry
+ *   groups     one entry per histogram (host, may be NULL; `capacity` entries)
+ *   hist       tjamd_length_freq[kept_count]: histogram g's entries at [groups[g].first, groups[g].first + groups[g].n_len)
+ * Returns the number of histograms. */
+typedef struct { int first, n_elem, n_context, mode, indel, n_len, modal_len, modal_freq; long long integral; } tjamd_context_group;
+typedef struct { int length, freq; } tjamd_length_freq;
+long tjamd_context_histograms (tjamd_counter *c, int max_distance_per_flank, int levenshtein_distance, int *group_of, int *join_type,
+                               tjamd_context_group *groups, tjamd_length_freq *hist, long capacity);
+
+/* release the calling thread's shared device contexts of the synchronous string scans (update_hopo_counter_from_seq on a
+ * counter that never read a file, tjamd_scan_windows) now; they are released by themselves when the thread ends */
+void tjamd_thread_cleanup (void);
 
 /* timing of the last operations on this counter, from HIP events on its stream (milliseconds) */
 double tjamd_last_scan_ms (tjamd_counter *c);       /* scan kernel(s) of the last tjamd_scan_* call */

@@ -228,8 +228,8 @@ orc_genomic_context_list (const hopo_element *elem, long n, int kmer_size, int m
  * base, context[0], context[1], length, all descending), so the union is the same two-way merge on that key with the
  * same tie rule.  That list (cat_sample / cat_index, one entry per record: which sample, which of its records) is the
  * reference's; the product keeps it collapsed: neighbours with one key become one union record with a count per sample
- * -- key fields and canon flag of the lowest-numbered sample that has the key, count field = total over the samples
- * (20-bit store), as tjamd_merge_samples documents.  rec3: tjamd_record triples {ctx0, ctx1, meta}; key = (base, ctx0,
+ * -- count field = total over the samples (20-bit store), canon flag = the strands any sample saw the key on (OR of the
+ * samples' flags), as tjamd_merge_samples documents.  rec3: tjamd_record triples {ctx0, ctx1, meta}; key = (base, ctx0,
  * ctx1, signed 10-bit length).  Outputs: cat_sample, cat_index (total records each, may be NULL), keys3 (3 words per
  * distinct key), counts (n_samples ints per key: signed 20-bit count of each sample, 0 if absent).
  * Returns the number of distinct keys. */
@@ -255,6 +255,7 @@ orc_merge_samples (const uint64_t *rec3, const long *counts_in, int n_samples, i
 {
   const uint64_t count_mask = 0xFFFFFULL << 12, field_mask = (1ULL << 52) - 1ULL;   /* (bits 52 and up of a device record are scratch) */
   long total = 0, s, n_out = 0, i, tot = 0;
+  uint64_t fl = 0;
   for (s = 0; s < n_samples; s++) total += counts_in[s];
   /* `cur` = the concatenated list so far (records tagged with their sample), `nxt` = after adding one more genome */
   uint64_t *cur = (uint64_t *) malloc ((size_t) (total > 0 ? total : 1) * 4 * sizeof (uint64_t)), *nxt = (uint64_t *) malloc ((size_t) (total > 0 ? total : 1) * 4 * sizeof (uint64_t));
@@ -280,12 +281,12 @@ orc_merge_samples (const uint64_t *rec3, const long *counts_in, int n_samples, i
     if (cat_index) cat_index[i] = (int) (cur[4 * i + 3] & 0xFFFFFFFFULL);
     if (i == 0 || orc_key_cmp_desc (cur + 4 * (i - 1), cur + 4 * i) != 0) {
       for (s = 0; s < n_samples; s++) counts[n_out * n_samples + s] = 0;
-      n_out++; tot = 0;
+      n_out++; tot = 0; fl = 0;
     }
     tot += cnt;
-    /* (on a tie the later sample comes first, so the last record of a run of equal keys is the lowest-numbered sample's) */
+    fl |= cur[4 * i + 2] & (7ULL << 49);
     keys3[3 * (n_out - 1)] = cur[4 * i]; keys3[3 * (n_out - 1) + 1] = cur[4 * i + 1];
-    keys3[3 * (n_out - 1) + 2] = ((cur[4 * i + 2] & field_mask) & ~count_mask) | (((uint64_t) tot & 0xFFFFFULL) << 12);
+    keys3[3 * (n_out - 1) + 2] = ((cur[4 * i + 2] & field_mask) & ~count_mask & ~(7ULL << 49)) | (((uint64_t) tot & 0xFFFFFULL) << 12) | fl;
     counts[(n_out - 1) * n_samples + smp] += cnt;
   }
   free (cur); free (nxt);

@@ -5,5 +5,5 @@ side is C and whose compute is hand-written HIP for gfx950.  This Python package
 tests and the benchmark; it holds no compute of its own and never touches oracle/.
 """
 from .build import build_library, library_path  # noqa: F401
-from .capi import (Counter, HopoCounter, Options, lib, device_count, synth_stream, ELEM_DTYPE, RECORD_DTYPE,  # noqa: F401
+from .capi import (Counter, Comm, HopoCounter, Options, lib, device_count, synth_stream, ELEM_DTYPE, RECORD_DTYPE,  # noqa: F401
                    LOCATED_DTYPE, GROUP_DTYPE, decode_meta, TatajubaAmdError, read_file_stream, EXPORTS)

@@ -18,6 +18,10 @@ ELEM_DTYPE = np.dtype([("ctx0", "<u8"), ("ctx1", "<u8"), ("meta", "<u8"), ("read
                        ("loc_ref_id", "<i4"), ("loc_pos", "<i4"), ("loc_last", "<i4")])
 RECORD_DTYPE = np.dtype([("ctx0", "<u8"), ("ctx1", "<u8"), ("meta", "<u8")])
 GROUP_DTYPE = np.dtype([("first", "<i4"), ("n_elem", "<i4"), ("n_context", "<i4"), ("mode", "<i4"), ("integral", "<i8")])
+# tjamd_context_group / tjamd_length_freq (include/tatajuba_amd.h)
+CONTEXT_GROUP_DTYPE = np.dtype([("first", "<i4"), ("n_elem", "<i4"), ("n_context", "<i4"), ("mode", "<i4"), ("indel", "<i4"), ("n_len", "<i4"),
+                                ("modal_len", "<i4"), ("modal_freq", "<i4"), ("integral", "<i8")])
+LENGTH_FREQ_DTYPE = np.dtype([("length", "<i4"), ("freq", "<i4")])
 LOCATED_DTYPE = np.dtype([("ctx0", "<u8"), ("ctx1", "<u8"), ("meta", "<u8"), ("pos", "<u8")])
 
 
@@ -80,12 +84,13 @@ EXPORTS = [
     "distance_between_single_context_kmer", "distance_between_context_kmer_pair", "distance_between_context_kmer_pair_with_edit_shift",
     "leftmost_hopo_name_and_length_from_string", "hopo_counter_histogram_integral",
     "dna_in_2_bits", "bit_2_dna",
-    "tjamd_device_count", "tjamd_last_error", "tjamd_version", "tjamd_counter_create", "tjamd_counter_destroy",
+    "tjamd_device_count", "tjamd_source_hash", "tjamd_last_error", "tjamd_version", "tjamd_counter_create", "tjamd_counter_destroy",
     "tjamd_counter_reset", "tjamd_counter_set_stream", "tjamd_counter_device", "tjamd_scan_device", "tjamd_scan_host",
     "tjamd_scan_host_located", "tjamd_read_file_stream_mt", "tjamd_host_alloc", "tjamd_host_free", "tjamd_device_alloc", "tjamd_device_free", "tjamd_device_download", "tjamd_sync", "tjamd_mark", "tjamd_wait_mark", "tjamd_reserve", "tjamd_raw_count",
     "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_finalise_begin", "tjamd_finalise_end", "tjamd_kept_count",
     "tjamd_n_idx", "tjamd_coverage", "tjamd_download_kept", "tjamd_download_idx", "tjamd_kept_device_ptr",
-    "tjamd_merge_samples", "tjamd_gather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_scan_windows", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches",
+    "tjamd_merge_samples", "tjamd_gather_histograms", "tjamd_peer_access_report", "tjamd_comm_unique_id", "tjamd_comm_create", "tjamd_comm_destroy",
+    "tjamd_comm_set_stream", "tjamd_comm_rank", "tjamd_comm_world", "tjamd_comm_collectives", "tjamd_allgather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_context_histograms", "tjamd_scan_windows", "tjamd_thread_cleanup", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches",
     "tjamd_synth_stream", "tjamd_read_file_stream",
 ]
 
@@ -177,6 +182,21 @@ def lib():
     L.tjamd_tract_ids.restype = C.c_long; L.tjamd_tract_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
     L.tjamd_group_contexts.restype = C.c_long
     L.tjamd_group_contexts.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    L.tjamd_comm_unique_id.argtypes = [C.c_void_p]
+    L.tjamd_comm_create.restype = C.c_void_p; L.tjamd_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.tjamd_comm_destroy.restype = None; L.tjamd_comm_destroy.argtypes = [C.c_void_p]
+    L.tjamd_comm_rank.argtypes = [C.c_void_p]; L.tjamd_comm_world.argtypes = [C.c_void_p]
+    L.tjamd_comm_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.tjamd_comm_collectives.restype = C.c_long; L.tjamd_comm_collectives.argtypes = [C.c_void_p]
+    L.tjamd_allgather_histograms.restype = C.c_long
+    L.tjamd_allgather_histograms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_long)]
+    L.tjamd_peer_access_report.argtypes = [C.c_char_p, C.c_int]
+    L.tjamd_context_histograms.restype = C.c_long
+    L.tjamd_context_histograms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    # (without these ctypes truncates the 64-bit device pointer to a C int)
+    L.tjamd_device_alloc.restype = C.c_void_p; L.tjamd_device_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    L.tjamd_device_free.restype = None; L.tjamd_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.tjamd_device_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.tjamd_scan_windows.restype = C.c_long
     L.tjamd_scan_windows.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
     U64P = C.POINTER(C.c_uint64)
@@ -248,6 +268,50 @@ def read_file_stream(path):
     got = lib().tjamd_read_file_stream(os.fsencode(path), out.ctypes.data, need, C.byref(n))
     assert got == need
     return out[:need], n.value
+
+
+class Comm:
+    """tjamd_comm: the process-per-GPU exchange of the C library (ncclAllGather over RCCL behind tjamd_allgather_histograms)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        """rank 0: the bytes every rank passes to Comm(...) (hand them over with whatever the job has: MPI, a file, a store)"""
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        if lib().tjamd_comm_unique_id(buf) != 0:
+            raise TatajubaAmdError(_err())
+        return buf.raw
+
+    def __init__(self, counter, ident, rank, world):
+        self.world = world
+        self._id = C.create_string_buffer(bytes(ident), Comm.ID_BYTES)
+        self._h = lib().tjamd_comm_create(counter._h, self._id, rank, world)
+        if not self._h:
+            raise TatajubaAmdError(_err())
+
+    def set_stream(self, hip_stream):
+        if lib().tjamd_comm_set_stream(self._h, C.c_void_p(hip_stream)) != 0:
+            raise TatajubaAmdError(_err())
+
+    def allgather(self, counter):
+        """(device pointer of all ranks' kept records back to back, ctypes long array of records per rank, total)"""
+        ptr, cnt = C.c_void_p(), (C.c_long * self.world)()
+        tot = lib().tjamd_allgather_histograms(counter._h, self._h, C.byref(ptr), cnt)
+        if tot < 0:
+            raise TatajubaAmdError(_err())
+        return ptr, cnt, tot
+
+    @property
+    def collectives(self):
+        return lib().tjamd_comm_collectives(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tjamd_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 class Counter:
@@ -364,6 +428,17 @@ class Counter:
         grp = np.zeros(max(n, 1), dtype=GROUP_DTYPE)
         ng = self._chkn(lib().tjamd_group_contexts(self._h, max_distance_per_flank, gof.ctypes.data, grp.ctypes.data, n))
         return gof[:n], grp[:ng]
+
+    def context_histograms(self, max_distance_per_flank, levenshtein_distance):
+        """tjamd_context_histograms: dict of group_of, join_type (int32[n_kept]), groups (CONTEXT_GROUP_DTYPE), hist
+        (LENGTH_FREQ_DTYPE[n_kept]: histogram g's entries at [first, first + n_len))"""
+        n = self.n_kept
+        gof, jt = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        grp = np.zeros(max(n, 1), dtype=CONTEXT_GROUP_DTYPE)
+        hist = np.zeros(max(n, 1), dtype=LENGTH_FREQ_DTYPE)
+        ng = self._chkn(lib().tjamd_context_histograms(self._h, max_distance_per_flank, levenshtein_distance, gof.ctypes.data, jt.ctypes.data,
+                                                       grp.ctypes.data, hist.ctypes.data, n))
+        return {"group_of": gof[:n], "join_type": jt[:n], "groups": grp[:ng], "hist": hist[:n]}
 
     def last_scan_launches(self):
         return int(lib().tjamd_last_scan_launches(self._h))

@@ -19,6 +19,9 @@
 // storage -> aggregation kernels -> radix sort / scans (fallback paths, merge) -> bin kernels -> host layer (tjamd_*).
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <mutex>
+#include <new>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -53,7 +56,8 @@ static int set_err (int code, const char *fmt, ...)
   set_err (TJAMD_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString (e_), __FILE__, __LINE__); return NULL; } } while (0)
 
 extern "C" const char *tjamd_last_error (void) { return g_err; }
-extern "C" const char *tjamd_version (void) { return "tatajuba_amd 0.1 (gfx950)"; }
+// (for the C half of the library, hopo_host.c; not exported)
+extern "C" void tj_set_last_error (const char *msg) { (void) set_err (TJAMD_ERR_ARG, "%s", msg ? msg : "error"); }
 
 extern "C" int tjamd_device_count (void)
 {
@@ -3222,16 +3226,17 @@ void bin_merge_kernel (const u64 *__restrict__ rec, const u32 *__restrict__ bins
       if (t < s) {
         const u64 a0 = R[3 * t], a1 = R[3 * t + 1], al = R[3 * t + 2] & lmask;
         rep = true;
-        u32 tot = 0, r = 0;
+        u32 tot = 0, r = 0, fl = 0;
         for (u32 j = 0; j < s; j++) {
           const u64 b0 = R[3 * j], b1 = R[3 * j + 1], bm = R[3 * j + 2], bl = bm & lmask;
           const bool same = (b0 == a0) & (b1 == a1) & (bl == al);
           const bool before = (b0 > a0) | ((b0 == a0) & ((b1 > a1) | ((b1 == a1) & (bl > al))));
           r += before ? 1u : 0u;
-          if (same) { if (j < t) rep = false; tot += (u32) meta_count (bm); }
+          if (same) { if (j < t) rep = false; tot += (u32) meta_count (bm); fl |= (u32) (bm >> TJ_META_FLAG_SHIFT) & 7u; }
         }
         H[t] = r | (rep ? 0x80000000u : 0u);
-        ttot[st + t] = rep ? tot : 0xFFFFFFFFu;
+        // (the key's depth over all samples, 20-bit store, and the strands any sample saw it on)
+        ttot[st + t] = rep ? ((tot & 0xFFFFFu) | (fl << 28)) : 0xFFFFFFFFu;
       }
       nrep += (u32) __popcll (__ballot (rep));
     }
@@ -3270,6 +3275,7 @@ void bin_merge_write_kernel (const u64 *__restrict__ rec, const u32 *__restrict_
             for (int q = 0; q < n_samples; q++) counts[u * n_samples + q] = 0;
             u64 m = am & ((1ull << TJ_META_SAMPLE_SHIFT) - 1ull);
             m = (m & ~(0xFFFFFull << TJ_META_COUNT_SHIFT)) | (((u64) tot & 0xFFFFFull) << TJ_META_COUNT_SHIFT);
+            m = (m & ~(7ull << TJ_META_FLAG_SHIFT)) | ((u64) ((tot >> 28) & 7u) << TJ_META_FLAG_SHIFT);
             keys[3 * u] = a0; keys[3 * u + 1] = a1; keys[3 * u + 2] = m;
           }
         }
@@ -3302,7 +3308,7 @@ __global__ void merge_tag_kernel (const u64 *__restrict__ in, u64 *__restrict__ 
 }
 
 __global__ void merge_write_kernel (const u64 *__restrict__ rec, long n, const u32 *__restrict__ flags, const u32 *__restrict__ segid,
-                                    int n_samples, u64 *__restrict__ keys, int *__restrict__ counts, u32 *__restrict__ totals, long cap)
+                                    int n_samples, u64 *__restrict__ keys, int *__restrict__ counts, u32 *__restrict__ totals, u32 *__restrict__ orflags, long cap)
 {
   for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
     const u32 seg = segid[i] + flags[i] - 1u;           // exclusive scan of the head flags: heads before i (+ itself) - 1
@@ -3312,16 +3318,18 @@ __global__ void merge_write_kernel (const u64 *__restrict__ rec, long n, const u
     const int cnt = meta_count (meta);
     counts[(long) seg * n_samples + sample] = cnt;
     atomicAdd (&totals[seg], (u32) cnt);
+    atomicOr (&orflags[seg], (u32) (meta >> TJ_META_FLAG_SHIFT) & 7u);
     if (flags[i]) { keys[3 * (long) seg] = rec[3 * i]; keys[3 * (long) seg + 1] = rec[3 * i + 1]; keys[3 * (long) seg + 2] = meta; }
   }
 }
 
-__global__ void merge_totals_kernel (u64 *__restrict__ keys, const u32 *__restrict__ totals, const u32 *n_seg_p, long cap)
-{ // count field := depth over all samples (20-bit store), canon_flag as in the first sample that has the key
+__global__ void merge_totals_kernel (u64 *__restrict__ keys, const u32 *__restrict__ totals, const u32 *__restrict__ orflags, const u32 *n_seg_p, long cap)
+{ // count field := depth over all samples (20-bit store), canon_flag := the strands any sample saw the key on
   const long n_seg = min ((long) *n_seg_p, cap);
   for (long j = blockIdx.x * (long) blockDim.x + threadIdx.x; j < n_seg; j += (long) gridDim.x * blockDim.x) {
     u64 m = keys[3 * j + 2] & ((1ull << TJ_META_SAMPLE_SHIFT) - 1ull);
     m = (m & ~(0xFFFFFull << TJ_META_COUNT_SHIFT)) | (((u64) totals[j] & 0xFFFFFull) << TJ_META_COUNT_SHIFT);
+    m = (m & ~(7ull << TJ_META_FLAG_SHIFT)) | ((u64) (orflags[j] & 7u) << TJ_META_FLAG_SHIFT);
     keys[3 * j + 2] = m;
   }
 }
@@ -3362,7 +3370,7 @@ struct tjamd_counter
   u64 raw_bound = 0;          // upper bound of the raw records in the buckets (exact after a synchronisation)
   long n_undefined = 0;
   double slack = 1.0;
-  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov, bins, binstart, binctx, ovf;
+  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov, bins, binstart, binctx, ovf, grp_jt, grp_hist;
   u32 bin_rank_max = BS_RANK_MAX;
   FinCounts *d_fin = nullptr, *h_fin = nullptr;
   struct DevState *d_state = nullptr, *h_state = nullptr;   // ctr, fin and cursors live in one block: one copy brings all three to the host
@@ -3445,7 +3453,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   (void) hipSetDevice (c->device);
   (void) hipStreamSynchronize (c->stream);
   DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->slow, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
-                   &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx, &c->ovf};
+                   &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx, &c->ovf, &c->grp_jt, &c->grp_hist};
   for (DevBuf *b : all) release (*b);
   for (hipEvent_t ev : c->marks) if (ev) (void) hipEventDestroy (ev);
   if (c->d_state) (void) hipFree (c->d_state);
@@ -4357,6 +4365,235 @@ extern "C" long tjamd_group_contexts (tjamd_counter *c, int max_distance_per_fla
   return (long) ng;
 }
 
+// ---- the whole grouping step of new_genomic_context_list (reference: src/context_histogram.c:245-270): an element that
+// fails the flank-distance test against the histogram being built is tried again with an edit distance between the two
+// "left.B.right" names (:19-23, :255-261: joins if it is below opt.levenshtein_distance and marks the histogram `indel`),
+// then every histogram gets its tract-length histogram (:278-286).
+//
+// The retry makes the step sequential in principle: whether element i joins depends on which element currently carries
+// the histogram's name (the one with the highest count so far).  On the device it is speculated: (1) the grouping without
+// the retry (group_back / group_resolve above) is computed in parallel; (2) every element that opens a group there is
+// tested, in parallel, against the name the group before it ends up with -- which is what the sequential pass would test it
+// against as long as no retry has succeeded since the last point where both agree; (3) where such a test succeeds (rare:
+// unrelated contexts are a dozen edits apart) one thread replays the reference's loop from there until it opens a group at
+// an element that opens one in (1) as well -- from that element on the two passes are in the same state again.
+//
+// The edit distance stands for biomcmc_levenshtein_distance (s1, n, s2, n, 1, 1, true) of biomcmc-lib, whose source is
+// absent from the reference tree: unit-cost global edit distance (UNPINNED, see oracle/context_oracle.c).
+
+__device__ __forceinline__ u32 name_symbol (u64 c0, u64 c1, u32 base, int k, int t)
+{ // t-th character of generate_name_from_flanking_contexts (context, base, k, false) as a small integer ('.' = 4)
+  if (t < k) return (u32) (c0 >> (2 * t)) & 3u;
+  if (t == k + 1) return base;
+  if (t < k + 3) return 4u;
+  return (u32) (c1 >> (2 * (t - k - 3))) & 3u;
+}
+
+__device__ int name_edit_distance (const u64 *__restrict__ kept, long a, long b, int k)
+{
+  const u64 a0 = kept[3 * a], a1 = kept[3 * a + 1], b0 = kept[3 * b], b1 = kept[3 * b + 1];
+  const u32 ab = (u32) (kept[3 * a + 2] & 3ull), bb = (u32) (kept[3 * b + 2] & 3ull);
+  const int n = 2 * k + 3;
+  unsigned char row[2 * 32 + 4];
+  for (int y = 0; y <= n; y++) row[y] = (unsigned char) y;
+  for (int x = 1; x <= n; x++) {
+    const u32 sb = name_symbol (b0, b1, bb, k, x - 1);
+    int diag = row[0];
+    row[0] = (unsigned char) x;
+    for (int y = 1; y <= n; y++) {
+      const int up = row[y];
+      int best = diag + (name_symbol (a0, a1, ab, k, y - 1) == sb ? 0 : 1);
+      best = min (best, min ((int) row[y - 1], up) + 1);
+      diag = up; row[y] = (unsigned char) best;
+    }
+  }
+  return row[n];
+}
+
+// join types on the device: 0 opened its histogram, 1 joined within the flank distance and met its own context in the
+// list, 5 joined within the flank distance and added a context, 2 taken in by the retry (always adds a context); the host
+// sees type & 3
+#define GJ_ADDS_CONTEXT(t) ((t) != 1)
+
+// (2): elements that open a group in the grouping without the retry, tested against the name of the group before them
+__global__ void group_speculate_kernel (const u64 *__restrict__ kept, long n, int k, int lev, const u32 *__restrict__ head,
+                                        u32 *__restrict__ cand, int *__restrict__ jt, u32 *__restrict__ n_cand)
+{
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
+    u32 c = 0;
+    // (without the retry every context of a histogram is within the flank distance of every other, the distance loop runs
+    // through all of them, and an identical context -- the element before, in the sorted array -- is met)
+    jt[i] = head[i] ? 0 : ((kept[3 * i] == kept[3 * (i - 1)] && kept[3 * i + 1] == kept[3 * (i - 1) + 1]) ? 1 : 5);
+    if (head[i] && i > 0 && ((kept[3 * i + 2] ^ kept[3 * (i - 1) + 2]) & 3ull) == 0ull) {
+      long ph = i - 1;
+      while (!head[ph]) ph--;
+      long mode = ph;
+      int mc = meta_count (kept[3 * ph + 2]);
+      for (long j = ph + 1; j < i; j++) { const int cj = meta_count (kept[3 * j + 2]); if (cj > mc) { mc = cj; mode = j; } }
+      if (name_edit_distance (kept, mode, i, k) < lev) { c = 1u; atomicAdd (n_cand, 1u); }
+    }
+    cand[i] = c;
+  }
+}
+
+// (3): one workgroup walks the candidates in order; thread 0 replays the reference's loop from each one that lies past
+// the stretch the replay before it covered.  Once a histogram holds a context that came in through the retry its contexts
+// are no longer all close to one another, and the reference's distance loop (src/context_histogram.c:36-46) matters as
+// written: contexts in the order they were added, give up at the first one 2 * max_distance or more away, stop with
+// distance 0 at an identical one (whatever comes after it), otherwise the largest distance met.
+#define GR_CHUNK 4096
+__global__ __launch_bounds__ (256)
+void group_repair_kernel (const u64 *__restrict__ kept, long n, int k, int maxd, int lev,
+                          u32 *__restrict__ head, const u32 *__restrict__ cand, int *__restrict__ jt)
+{
+  __shared__ long s_pos, s_min;
+  if (threadIdx.x == 0) s_pos = 0;
+  __syncthreads ();
+  for (;;) {
+    const long start = s_pos;
+    if (start >= n) break;
+    if (threadIdx.x == 0) s_min = n;
+    __syncthreads ();
+    const long end = min (n, start + (long) GR_CHUNK);
+    for (long i = start + threadIdx.x; i < end; i += blockDim.x)
+      if (cand[i]) { atomicMin ((unsigned long long *) &s_min, (unsigned long long) i); break; }
+    __syncthreads ();
+    const long h = s_min;
+    if (threadIdx.x == 0) {
+      if (h >= n) s_pos = end;
+      else {
+        long hd = h - 1;
+        while (!head[hd]) hd--;                           // (flags before h are final: h lies past every earlier replay)
+        long mode = hd;
+        int mc = meta_count (kept[3 * hd + 2]);
+        for (long j = hd + 1; j < h; j++) { const int cj = meta_count (kept[3 * j + 2]); if (cj > mc) { mc = cj; mode = j; } }
+        long i = h;
+        while (i < n) {
+          if ((kept[3 * i + 2] ^ kept[3 * hd + 2]) & 3ull) break;          // another base: opens a group in both passes, untouched
+          const u64 c0 = kept[3 * i], c1 = kept[3 * i + 1];
+          int this_max = 0;
+          bool fail = false, matched = false;
+          for (long j = hd; j < i && !fail && !matched; j++) {
+            if (j > hd && !GJ_ADDS_CONTEXT (jt[j])) continue;
+            int d = min (flank_hamming (kept[3 * j], c0), 2 * maxd);
+            if (d >= 2 * maxd) { fail = true; break; }
+            d += min (flank_hamming (kept[3 * j + 1], c1), 2 * maxd - d);
+            if (d >= 2 * maxd) { fail = true; break; }
+            this_max = max (this_max, d);
+            if (d == 0) matched = true;
+          }
+          int type = 0;
+          if (!fail && (matched ? 0 : this_max) < maxd) type = matched ? 1 : 5;
+          else if (name_edit_distance (kept, mode, i, k) < lev) type = 2;  // the indel retry
+          if (type) {
+            head[i] = 0u; jt[i] = type;
+            const int ci = meta_count (kept[3 * i + 2]);
+            if (ci > mc) { mc = ci; mode = i; }
+            i++;
+          }
+          else {
+            const bool was_head = head[i] != 0u;
+            head[i] = 1u; jt[i] = 0; hd = i; mode = i; mc = meta_count (kept[3 * i + 2]);
+            i++;
+            if (was_head) break;                          // both passes open a group here: the same state from now on
+          }
+        }
+        s_pos = i;
+      }
+    }
+    __syncthreads ();
+  }
+}
+
+struct CtxGroupOut { int first, n_elem, n_context, mode, indel, n_len, modal_len, modal_freq; long long integral; };
+struct LenFreq { int length, freq; };
+
+__global__ void group_histogram_kernel (const u64 *__restrict__ kept, long n, const u32 *__restrict__ head, const u32 *__restrict__ gid_excl,
+                                        int *__restrict__ jt, int *__restrict__ group_of, CtxGroupOut *__restrict__ groups, LenFreq *__restrict__ hist)
+{
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
+    if (!head[i]) continue;
+    const int g = (int) gid_excl[i];
+    CtxGroupOut o = {(int) i, 0, 0, (int) i, 0, 0, 0, 0, 0};
+    int mode_count = 0;
+    LenFreq *h = hist + i;                              // (a histogram has at most as many lengths as its group has elements)
+    for (long j = i; j < n && (j == i || !head[j]); j++) {
+      const u64 m = kept[3 * j + 2];
+      const int cnt = meta_count (m);
+      int len = (int) ((m >> TJ_META_LEN_SHIFT) & 0x3FFull);
+      if (len & 0x200) len -= 0x400;                    // signed 10-bit field
+      // contexts of the histogram (reference: context_histogram_add_hopo_elem, src/context_histogram.c:184-190): one more unless
+      // the distance loop met an identical context; an element taken in by the indel retry is appended whatever the list holds
+      const int t = jt[j];
+      if (j == i || GJ_ADDS_CONTEXT (t)) o.n_context++;
+      if (t == 2) o.indel = 1;
+      jt[j] = t & 3;
+      if (j == i || mode_count < cnt) { mode_count = cnt; o.mode = (int) j; }
+      o.integral += cnt; o.n_elem++;
+      int q = 0;
+      while (q < o.n_len && h[q].length != len) q++;
+      if (q == o.n_len) { h[q].length = len; h[q].freq = 0; o.n_len++; }
+      h[q].freq += cnt;
+      group_of[j] = g;
+    }
+    for (int a = 1; a < o.n_len; a++) {                 // highest summed count first, then the larger length (insertion sort: a few entries)
+      const LenFreq x = h[a];
+      int b = a - 1;
+      while (b >= 0 && (h[b].freq < x.freq || (h[b].freq == x.freq && h[b].length < x.length))) { h[b + 1] = h[b]; b--; }
+      h[b + 1] = x;
+    }
+    o.modal_len = h[0].length; o.modal_freq = h[0].freq;
+    groups[g] = o;
+  }
+}
+
+extern "C" long tjamd_context_histograms (tjamd_counter *c, int max_distance_per_flank, int levenshtein_distance, int *group_of, int *join_type,
+                                          tjamd_context_group *groups, tjamd_length_freq *hist, long capacity)
+{
+  if (!c || max_distance_per_flank < 0) return -set_err (TJAMD_ERR_ARG, "bad arguments");
+  if (c->status < 0) return -set_err (TJAMD_ERR_STATE, "tjamd_context_histograms needs a finalised counter");
+  if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
+  const long n = c->n_kept;
+  if (n == 0) return 0;
+  static_assert (sizeof (CtxGroupOut) == sizeof (tjamd_context_group) && sizeof (LenFreq) == sizeof (tjamd_length_freq), "group layout");
+  int rc = ensure (c->headpos, (size_t) n * 4, c->stream);          // back[]
+  if (!rc) rc = ensure (c->flags, (size_t) n * 4, c->stream);      // head flags
+  if (!rc) rc = ensure (c->outpos, (size_t) n * 4, c->stream);     // groups before each element
+  if (!rc) rc = ensure (c->segid, (size_t) n * 4, c->stream);      // group_of
+  if (!rc) rc = ensure (c->keep, (size_t) n * 4, c->stream);       // candidates of the retry
+  if (!rc) rc = ensure (c->grp_jt, (size_t) n * 4, c->stream);
+  if (!rc) rc = ensure (c->grp_hist, (size_t) n * sizeof (LenFreq), c->stream);
+  if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n) * 4 + 64, c->stream);
+  if (!rc) rc = ensure (c->alt, (size_t) n * sizeof (CtxGroupOut), c->stream);
+  if (rc) return -rc;
+  const u64 *kept = (const u64 *) c->kept.p;
+  u32 *total = (u32 *) c->scan_tmp.p + scan_tmp_words (n), *n_cand = total + 1;
+  hipLaunchKernelGGL (group_back_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, kept, n, max_distance_per_flank, (int *) c->headpos.p);
+  hipLaunchKernelGGL (group_resolve_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const int *) c->headpos.p, n, (u32 *) c->flags.p);
+  if (hipMemsetAsync (n_cand, 0, 4, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "memset failed");
+  hipLaunchKernelGGL (group_speculate_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, kept, n, c->k, levenshtein_distance,
+                      (const u32 *) c->flags.p, (u32 *) c->keep.p, (int *) c->grp_jt.p, n_cand);
+  u32 nc = 0;
+  if (hipMemcpyAsync (&nc, n_cand, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize (c->stream) != hipSuccess)
+    return -set_err (TJAMD_ERR_HIP, "grouping failed: %s", hipGetErrorString (hipGetLastError ()));
+  if (nc) hipLaunchKernelGGL (group_repair_kernel, dim3 (1), dim3 (256), 0, c->stream, kept, n, c->k, max_distance_per_flank, levenshtein_distance,
+                              (u32 *) c->flags.p, (const u32 *) c->keep.p, (int *) c->grp_jt.p);
+  rc = exclusive_scan (c, (const u32 *) c->flags.p, (u32 *) c->outpos.p, n, total, (u32 *) c->scan_tmp.p, scan_tmp_words (n));
+  if (rc) return -rc;
+  hipLaunchKernelGGL (group_histogram_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, kept, n, (const u32 *) c->flags.p, (const u32 *) c->outpos.p,
+                      (int *) c->grp_jt.p, (int *) c->segid.p, (CtxGroupOut *) c->alt.p, (LenFreq *) c->grp_hist.p);
+  if (hipGetLastError () != hipSuccess) return -set_err (TJAMD_ERR_HIP, "grouping launch failed");
+  u32 ng = 0;
+  if (hipMemcpyAsync (&ng, total, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize (c->stream) != hipSuccess)
+    return -set_err (TJAMD_ERR_HIP, "grouping failed: %s", hipGetErrorString (hipGetLastError ()));
+  if ((long) ng > capacity && groups) return -set_err (TJAMD_ERR_CAPACITY, "%u groups, caller capacity %ld", ng, capacity);
+  if (group_of && hipMemcpy (group_of, c->segid.p, (size_t) n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  if (join_type && hipMemcpy (join_type, c->grp_jt.p, (size_t) n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  if (groups && hipMemcpy (groups, c->alt.p, (size_t) ng * sizeof (CtxGroupOut), hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  if (hist && hipMemcpy (hist, c->grp_hist.p, (size_t) n * sizeof (LenFreq), hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+  return (long) ng;
+}
+
 // Tract ids on a merged union (reference: src/genome_set.c:207-221: the id goes up wherever two neighbours of the
 // concatenated list do not overlap; context-keyed: wherever (base, ctx0, ctx1) changes).  d_keys: tjamd_record[n] in the
 // reference's descending order, as tjamd_merge_samples writes them.
@@ -4394,6 +4631,44 @@ extern "C" long tjamd_tract_ids (tjamd_counter *c, const void *d_keys, long n, i
   return (long) nh + 1;
 }
 
+// Peer access between two devices of this process, asked for once per ordered pair: with it hipMemcpyPeerAsync moves the
+// bytes over xGMI directly, without it the runtime stages them through host memory.  Returns 1 direct, 0 staged;
+// tjamd_peer_access_report () says which pairs are which.
+static std::mutex g_peer_mutex;
+static signed char g_peer[64][64];                      // 0 unknown, 1 direct, -1 refused
+static int peer_access (int dst_dev, int src_dev)
+{
+  if (dst_dev == src_dev) return 1;
+  if (dst_dev < 0 || src_dev < 0 || dst_dev >= 64 || src_dev >= 64) return 0;
+  std::lock_guard<std::mutex> lock (g_peer_mutex);
+  if (g_peer[dst_dev][src_dev]) return g_peer[dst_dev][src_dev] > 0;
+  int can = 0, prev = -1;
+  (void) hipGetDevice (&prev);
+  if (hipDeviceCanAccessPeer (&can, dst_dev, src_dev) == hipSuccess && can && hipSetDevice (dst_dev) == hipSuccess) {
+    const hipError_t e = hipDeviceEnablePeerAccess (src_dev, 0);
+    can = (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled);
+    (void) hipGetLastError ();
+  }
+  else can = 0;
+  if (prev >= 0) (void) hipSetDevice (prev);
+  g_peer[dst_dev][src_dev] = can ? 1 : -1;
+  return can;
+}
+
+extern "C" int tjamd_peer_access_report (char *out, int capacity)
+{ // "dst<-src:direct" / "dst<-src:staged" for every pair a gather has used so far; returns the number of staged pairs
+  int staged = 0, at = 0;
+  std::lock_guard<std::mutex> lock (g_peer_mutex);
+  if (out && capacity > 0) out[0] = 0;
+  for (int d = 0; d < 64; d++)
+    for (int sdev = 0; sdev < 64; sdev++)
+      if (g_peer[d][sdev]) {
+        if (g_peer[d][sdev] < 0) staged++;
+        if (out && at < capacity - 24) at += snprintf (out + at, (size_t) (capacity - at), "%d<-%d:%s ", d, sdev, g_peer[d][sdev] > 0 ? "direct" : "staged");
+      }
+  return staged;
+}
+
 // The exchange of the cross-sample merge for a caller that, like the reference, runs its samples as threads of ONE
 // process (src/genome_set.c:66-94; merge at :195-229): the kept records of the finalised counters `samples` -- each on
 // the device its thread bound it to -- are copied into one buffer on dst's device (peer copies over xGMI between
@@ -4416,6 +4691,7 @@ extern "C" long tjamd_gather_histograms (tjamd_counter *dst, tjamd_counter *cons
     const size_t bytes = (size_t) counts[i] * 24;
     if (!bytes) continue;
     tjamd_counter *s = samples[i];
+    if (s->device != dst->device) peer_access (dst->device, s->device);   // (direct xGMI copies; staged through the host by the runtime where it is refused)
     hipError_t e = (s->device == dst->device)
       ? hipMemcpyAsync ((char *) dst->rawlist.p + off, s->kept.p, bytes, hipMemcpyDeviceToDevice, dst->stream)
       : hipMemcpyPeerAsync ((char *) dst->rawlist.p + off, dst->device, s->kept.p, s->device, bytes, dst->stream);
@@ -4486,7 +4762,7 @@ static long merge_samples_radix (tjamd_counter *c, const void *d_records, long n
   if (!rc) rc = ensure (c->alt, (size_t) n * 24, c->stream);
   if (!rc) rc = ensure (c->flags, (size_t) n * 4, c->stream);
   if (!rc) rc = ensure (c->segid, (size_t) n * 4, c->stream);
-  if (!rc) rc = ensure (c->keep, (size_t) n * 4, c->stream);          // totals per union key
+  if (!rc) rc = ensure (c->keep, (size_t) n * 8, c->stream);          // totals per union key, then their flags
   if (!rc) rc = ensure (c->scan_tmp, scan_tmp_words (n) * 4, c->stream);
   if (rc) return -rc;
   hipLaunchKernelGGL (merge_tag_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) d_records, (u64 *) c->rawlist.p, n, (const long *) c->prefix.p, n_samples);
@@ -4503,11 +4779,160 @@ static long merge_samples_radix (tjamd_counter *c, const void *d_records, long n
   const long n_union = c->h_fin->n_seg;
   if (n_union > capacity) return -set_err (TJAMD_ERR_CAPACITY, "%ld union keys, caller capacity %ld", n_union, capacity);
   if (hipMemsetAsync (d_out_counts, 0, (size_t) n_union * n_samples * 4, c->stream) != hipSuccess ||
-      hipMemsetAsync (c->keep.p, 0, (size_t) n_union * 4, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "memset failed");
+      hipMemsetAsync (c->keep.p, 0, (size_t) n * 8, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "memset failed");
   hipLaunchKernelGGL (merge_write_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) a, n, (const u32 *) flags, (const u32 *) segid,
-                      n_samples, (u64 *) d_out_keys, (int *) d_out_counts, (u32 *) c->keep.p, capacity);
+                      n_samples, (u64 *) d_out_keys, (int *) d_out_counts, (u32 *) c->keep.p, (u32 *) c->keep.p + n, capacity);
   hipLaunchKernelGGL (merge_totals_kernel, dim3 (grid_for (n_union)), dim3 (256), 0, c->stream, (u64 *) d_out_keys, (const u32 *) c->keep.p,
-                      (const u32 *) &c->d_fin->n_seg, capacity);
+                      (const u32 *) c->keep.p + n, (const u32 *) &c->d_fin->n_seg, capacity);
   if (hipGetLastError () != hipSuccess || hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "merge kernels failed");
   return n_union;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The exchange between PROCESSES, one per GPU: an all-gatherv of the finalised counters' kept records over RCCL (xGMI on
+// the node), so that every rank holds every sample's histogram for the cross-sample merge (reference attach point:
+// src/genome_set.c:195-229 -- there the samples are threads of one process and the "exchange" is a pointer).
+// RCCL has no all-gatherv: every rank contributes one block of the same size -- a header with its record count, then its
+// records -- to ONE ncclAllGather on the counter's stream, and a kernel packs the received blocks back to back.  The block
+// size is agreed without talking: it is a function of the counts of the exchange before (the same numbers on every
+// rank); the first exchange, and one in which some rank holds more than a block takes, learn the counts with an 8-byte
+// all-gather first.  One host synchronisation per exchange (the counts the caller gets back), on the usual path.
+
+struct tjamd_comm
+{
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  long cap = 0;                                         // records per block, 0 = not agreed yet
+  hipStream_t stream = nullptr;                         // tjamd_comm_set_stream; null: the stream of the counter being exchanged
+  DevBuf send, recv, out, dcounts;
+  long *h_counts = nullptr;                             // pinned, world entries
+  long exchanges = 0, collectives = 0;
+};
+
+#define NCCLCHK(call, ret) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+  set_err (TJAMD_ERR_HIP, "%s failed: %s", #call, ncclGetErrorString (r_)); return ret; } } while (0)
+
+extern "C" int tjamd_comm_unique_id (void *id_bytes)
+{
+  static_assert (TJAMD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  if (!id_bytes) return set_err (TJAMD_ERR_ARG, "tjamd_comm_unique_id: null buffer");
+  ncclUniqueId id;
+  NCCLCHK (ncclGetUniqueId (&id), TJAMD_ERR_HIP);
+  memcpy (id_bytes, &id, sizeof id);
+  return TJAMD_OK;
+}
+
+extern "C" tjamd_comm *tjamd_comm_create (tjamd_counter *c, const void *id_bytes, int rank, int world)
+{
+  if (!c || !id_bytes || world < 1 || world > 4096 || rank < 0 || rank >= world) { set_err (TJAMD_ERR_ARG, "tjamd_comm_create: bad arguments"); return NULL; }
+  HIPCHK_NULL (hipSetDevice (c->device));
+  tjamd_comm *m = new (std::nothrow) tjamd_comm;
+  if (!m) { set_err (TJAMD_ERR_HIP, "out of memory"); return NULL; }
+  m->rank = rank; m->world = world; m->device = c->device;
+  ncclUniqueId id;
+  memcpy (&id, id_bytes, sizeof id);
+  ncclResult_t r = ncclCommInitRank (&m->comm, world, id, rank);
+  if (r != ncclSuccess) { set_err (TJAMD_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString (r)); delete m; return NULL; }
+  if (hipHostMalloc ((void **) &m->h_counts, (size_t) world * sizeof (long), hipHostMallocDefault) != hipSuccess) {
+    set_err (TJAMD_ERR_HIP, "hipHostMalloc failed"); (void) ncclCommDestroy (m->comm); delete m; return NULL;
+  }
+  return m;
+}
+
+extern "C" void tjamd_comm_destroy (tjamd_comm *m)
+{
+  if (!m) return;
+  (void) hipSetDevice (m->device);
+  if (m->comm) (void) ncclCommDestroy (m->comm);
+  release (m->send); release (m->recv); release (m->out); release (m->dcounts);
+  if (m->h_counts) (void) hipHostFree (m->h_counts);
+  delete m;
+}
+
+extern "C" int tjamd_comm_set_stream (tjamd_comm *m, void *hip_stream)
+{
+  if (!m) return set_err (TJAMD_ERR_ARG, "tjamd_comm_set_stream: null communicator");
+  m->stream = (hipStream_t) hip_stream;
+  return TJAMD_OK;
+}
+extern "C" int tjamd_comm_rank (const tjamd_comm *m) { return m ? m->rank : -1; }
+extern "C" int tjamd_comm_world (const tjamd_comm *m) { return m ? m->world : -1; }
+extern "C" long tjamd_comm_collectives (const tjamd_comm *m) { return m ? m->collectives : -1; }
+
+#define GX_HEADER 16                                    // bytes in front of a block's records: the record count, then padding
+
+__global__ void gx_pack_kernel (const u64 *__restrict__ kept, long n, long cap, u64 *__restrict__ block)
+{ // header + the first min (n, cap) records
+  const long words = 3 * min (n, cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { block[0] = (u64) n; block[1] = 0; }
+  for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < words; i += (long) gridDim.x * blockDim.x) block[2 + i] = kept[i];
+}
+
+__global__ void gx_unpack_kernel (const u64 *__restrict__ recv, long block_words, int world, long cap, u64 *__restrict__ out, long *__restrict__ counts)
+{ // blocks -> records back to back in rank order; counts[r] = what rank r holds (may exceed cap: the caller looks)
+  for (int r = blockIdx.y; r < world; r += gridDim.y) {
+    long before = 0;
+    for (int q = 0; q < r; q++) before += min ((long) recv[(long) q * block_words], cap);
+    const u64 *src = recv + (long) r * block_words;
+    const long n = (long) src[0], words = 3 * min (n, cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[r] = n;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < words; i += (long) gridDim.x * blockDim.x) out[3 * before + i] = src[2 + i];
+  }
+}
+
+static long gx_block_cap (long max_count)
+{ // what a block takes after an exchange whose fullest rank held max_count: a quarter more, in steps of 4096 records
+  const long want = max_count + max_count / 4 + 1;
+  return ((want + 4095) / 4096) * 4096;
+}
+
+extern "C" long tjamd_allgather_histograms (tjamd_counter *c, tjamd_comm *m, const void **d_records, long *counts)
+{
+  if (!c || !m || !d_records || !counts) return -set_err (TJAMD_ERR_ARG, "tjamd_allgather_histograms: bad arguments");
+  if (c->status < 0) return -set_err (TJAMD_ERR_STATE, "tjamd_allgather_histograms needs a finalised counter");
+  if (c->device != m->device) return -set_err (TJAMD_ERR_ARG, "the communicator was made for device %d, the counter lives on %d", m->device, c->device);
+  if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
+  const int world = m->world;
+  const long n_mine = c->n_kept;
+  // (a stream of the communicator's own: the exchange of a finalised sample runs beside the scan of the next one; the
+  // caller has seen this counter's finalise end -- tjamd_finalise / tjamd_finalise_end -- so its kept records are complete)
+  const hipStream_t st = m->stream ? m->stream : c->stream;
+  int rc = ensure (m->dcounts, (size_t) (world + 1) * sizeof (long), st);
+  if (rc) return -rc;
+  long *d_counts = (long *) m->dcounts.p;
+  m->exchanges++;
+  for (int attempt = 0; attempt < 3; attempt++) {
+    if (m->cap == 0) {                                  // block size not agreed (first exchange, or the last one overflowed): the counts first
+      if (hipMemcpyAsync (d_counts + world, &n_mine, sizeof (long), hipMemcpyHostToDevice, st) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+      NCCLCHK (ncclAllGather (d_counts + world, d_counts, sizeof (long), ncclChar, m->comm, st), -TJAMD_ERR_HIP);
+      m->collectives++;
+      if (hipMemcpyAsync (m->h_counts, d_counts, (size_t) world * sizeof (long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize (st) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "exchange of the counts failed: %s", hipGetErrorString (hipGetLastError ()));
+      long mx = 0;
+      for (int r = 0; r < world; r++) mx = std::max (mx, m->h_counts[r]);
+      m->cap = gx_block_cap (mx);
+    }
+    const long cap = m->cap, block_words = GX_HEADER / 8 + 3 * cap;
+    rc = ensure (m->send, (size_t) block_words * 8, st);
+    if (!rc) rc = ensure (m->recv, (size_t) block_words * 8 * (size_t) world, st);
+    if (!rc) rc = ensure (m->out, (size_t) std::max<long> (cap * world, 1) * 24, st);
+    if (rc) return -rc;
+    hipLaunchKernelGGL (gx_pack_kernel, dim3 (grid_for (3 * std::min (n_mine, cap) + 1)), dim3 (256), 0, st, (const u64 *) c->kept.p, n_mine, cap, (u64 *) m->send.p);
+    NCCLCHK (ncclAllGather (m->send.p, m->recv.p, (size_t) block_words * 8, ncclChar, m->comm, st), -TJAMD_ERR_HIP);
+    m->collectives++;
+    hipLaunchKernelGGL (gx_unpack_kernel, dim3 (grid_for (3 * cap + 1), (unsigned) std::min (world, 64)), dim3 (256), 0, st,
+                        (const u64 *) m->recv.p, block_words, world, cap, (u64 *) m->out.p, d_counts);
+    if (hipGetLastError () != hipSuccess) return -set_err (TJAMD_ERR_HIP, "exchange launch failed");
+    if (hipMemcpyAsync (m->h_counts, d_counts, (size_t) world * sizeof (long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize (st) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "exchange failed: %s", hipGetErrorString (hipGetLastError ()));
+    long mx = 0, total = 0;
+    for (int r = 0; r < world; r++) { mx = std::max (mx, m->h_counts[r]); total += m->h_counts[r]; }
+    if (mx > cap) { m->cap = 0; continue; }             // (every rank sees the same counts and takes the same turn)
+    m->cap = gx_block_cap (mx);
+    for (int r = 0; r < world; r++) counts[r] = m->h_counts[r];
+    *d_records = m->out.p;
+    return total;
+  }
+  return -set_err (TJAMD_ERR_STATE, "the exchange did not settle on a block size");
 }

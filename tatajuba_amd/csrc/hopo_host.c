@@ -16,6 +16,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <limits.h>
+
+void tj_set_last_error (const char *msg);            /* hopo_device.hip: what tjamd_last_error () returns */
 
 /* ---- tables (reference: src/hopo_counter.c:10-11,205-216; constant here, so no lazy-initialisation race) -------- */
 
@@ -50,6 +53,16 @@ tj_fatal (const char *fmt, ...)
   va_start (ap, fmt); vfprintf (stderr, fmt, ap); va_end (ap);
   fprintf (stderr, "\n");
   exit (EXIT_FAILURE);
+}
+
+/* hc->n_elem is an int (reference src/hopo_counter.h:54): a sample with more raw tracts than that cannot be stated in
+ * the drop-in struct -- the reference would run into undefined behaviour there; stop instead of wrapping quietly */
+static int
+tj_n_elem (long n_host, long n_device, const char *name)
+{
+  if (n_host + n_device > (long) INT_MAX)
+    tj_fatal ("sample %s holds %ld homopolymer tracts, more than hopo_counter's int n_elem can state (%d)", name ? name : "?", n_host + n_device, INT_MAX);
+  return (int) (n_host + n_device);
 }
 
 static void
@@ -231,7 +244,7 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
         n = tjamd_raw_count (g.dev);
         if (n < 0) tj_fatal ("%s", tjamd_last_error ());
         tj_priv (h)->n_device = n;
-        h->n_elem = tj_priv (h)->n_host + (int) n;
+        h->n_elem = tj_n_elem (tj_priv (h)->n_host, n, h->name);
         return h;
       }                                                 /* (-1: cannot open / map -- the one-reader path reports it) */
     }
@@ -268,7 +281,7 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
   if (n < 0) tj_fatal ("%s", tjamd_last_error ());
   tj_pinned_put (buf[0]); tj_pinned_put (buf[1]);
   tj_priv (h)->n_device = n;
-  h->n_elem = tj_priv (h)->n_host + (int) n;
+  h->n_elem = tj_n_elem (tj_priv (h)->n_host, n, h->name);
   return h;
 }
 
@@ -375,7 +388,29 @@ update_hopo_counter_from_seq_all_monomers (hopo_counter hc, char *seq, int seq_l
  * more than the scans.  They share one context per calling thread and k-mer size, bound to the device that thread's
  * first counter was given (counters that scan files keep a context of their own: tj_device_counter). */
 #define TJ_SCRATCH_SLOTS 4
-static __thread struct { int k; tjamd_counter *dev; } tj_scratch[TJ_SCRATCH_SLOTS];
+typedef struct { int k; tjamd_counter *dev; } tj_scratch_slot;
+static __thread tj_scratch_slot tj_scratch[TJ_SCRATCH_SLOTS];
+static __thread int tj_scratch_next;                    /* the slot that is recycled next when all are taken */
+static pthread_key_t tj_scratch_key;                    /* its destructor releases a thread's contexts when the thread ends */
+static pthread_once_t tj_scratch_once = PTHREAD_ONCE_INIT;
+
+static void
+tj_scratch_release (void *slots)
+{
+  tj_scratch_slot *sl = (tj_scratch_slot *) slots;
+  int i;
+  if (!sl) return;
+  for (i = 0; i < TJ_SCRATCH_SLOTS; i++) if (sl[i].dev) { tjamd_counter_destroy (sl[i].dev); sl[i].dev = NULL; sl[i].k = 0; }
+}
+static void tj_scratch_make_key (void) { (void) pthread_key_create (&tj_scratch_key, tj_scratch_release); }
+
+/* release the calling thread's shared scan contexts now (a thread pool that outlives its work; the main thread before
+ * exit).  They are released by themselves when a thread ends. */
+void
+tjamd_thread_cleanup (void)
+{
+  tj_scratch_release (tj_scratch);
+}
 
 static tjamd_counter *
 tj_scratch_counter (int kmer_size)
@@ -386,8 +421,15 @@ tj_scratch_counter (int kmer_size)
   n = tjamd_device_count ();
   if (n <= 0) tj_fatal ("no HIP device is visible; the homopolymer scan runs on an MI355X only (there is no CPU fallback)");
   dev = pin ? atoi (pin) : (__atomic_fetch_add (&tj_next_device, 1, __ATOMIC_RELAXED) % n);
+  (void) pthread_once (&tj_scratch_once, tj_scratch_make_key);
+  (void) pthread_setspecific (tj_scratch_key, tj_scratch);       /* (the thread-local table itself: valid until the destructor has run) */
   for (i = 0; i < TJ_SCRATCH_SLOTS && tj_scratch[i].dev; i++) ;
-  if (i == TJ_SCRATCH_SLOTS) { tjamd_counter_destroy (tj_scratch[0].dev); i = 0; }      /* (more than four k-mer sizes in one thread: recycle) */
+  if (i == TJ_SCRATCH_SLOTS) {                          /* (more than four k-mer sizes in one thread: recycle them in turn) */
+    i = tj_scratch_next;
+    tj_scratch_next = (tj_scratch_next + 1) % TJ_SCRATCH_SLOTS;
+    tjamd_counter_destroy (tj_scratch[i].dev);
+    tj_scratch[i].dev = NULL;
+  }
   tj_scratch[i].k = kmer_size;
   tj_scratch[i].dev = tjamd_counter_create (dev, kmer_size);
   if (!tj_scratch[i].dev) tj_fatal ("%s", tjamd_last_error ());
@@ -408,6 +450,7 @@ tj_scan_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size)
   cap = (min_tract_size ? seq_length / 2 : seq_length) + 2;
   stream = (unsigned char *) malloc ((size_t) seq_length + 1);
   rec = (tjamd_located_record *) malloc ((size_t) cap * sizeof (tjamd_located_record));
+  if (!stream || !rec) tj_fatal ("out of memory (a string of %d bases)", seq_length);
   memcpy (stream, seq, (size_t) seq_length);
   stream[seq_length] = '\n';
   n = tjamd_scan_host_located (dev, stream, (size_t) seq_length + 1, min_tract_size, rec, cap);
@@ -417,6 +460,7 @@ tj_scan_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size)
     if (pv->n_host == hc->n_alloc) {
       hc->n_alloc *= 2;
       hc->elem = (hopo_element *) realloc (hc->elem, (size_t) hc->n_alloc * sizeof (hopo_element));
+      if (!hc->elem) tj_fatal ("out of memory (%d tract records)", hc->n_alloc);
     }
     e = hc->elem + pv->n_host++;
     e->context[0] = rec[i].ctx0; e->context[1] = rec[i].ctx1;
@@ -424,7 +468,7 @@ tj_scan_seq (hopo_counter hc, char *seq, int seq_length, int min_tract_size)
     e->read_offset = (int32_t) ((long) rec[i].pos - hc->kmer_size);
     e->loc_ref_id = e->loc_pos = e->loc_last = -1;
   }
-  hc->n_elem = pv->n_host + (int) pv->n_device;
+  hc->n_elem = tj_n_elem (pv->n_host, pv->n_device, hc->name);
   free (rec); free (stream);
 }
 
@@ -612,21 +656,28 @@ tjamd_scan_windows (int kmer_size, const char *const *seqs, const int *lens, int
   unsigned char *stream;
   long *start;
   long total = 0, n, i, cap, w = 0;
-  if (n_windows < 0 || (n_windows && (!seqs || !lens))) return -1;
+  if (n_windows < 0 || (n_windows && (!seqs || !lens))) { tj_set_last_error ("tjamd_scan_windows: bad arguments"); return -1; }
   start = (long *) malloc (((size_t) n_windows + 1) * sizeof (long));
+  if (!start) { tj_set_last_error ("tjamd_scan_windows: out of memory"); return -1; }
   for (i = 0; i < n_windows; i++) { start[i] = total; total += (lens[i] > 0 ? lens[i] : 0) + 1; }
   start[n_windows] = total;
   if (!total) { free (start); return 0; }
+  cap = (min_tract_size ? total / 2 : total) + 2;
   stream = (unsigned char *) malloc ((size_t) total);
+  rec = (tjamd_located_record *) malloc ((size_t) cap * sizeof (tjamd_located_record));
+  if (!stream || !rec) { free (stream); free (rec); free (start); tj_set_last_error ("tjamd_scan_windows: out of memory"); return -1; }
   for (i = 0; i < n_windows; i++) {
     if (lens[i] > 0) memcpy (stream + start[i], seqs[i], (size_t) lens[i]);
     stream[start[i + 1] - 1] = '\n';
   }
-  cap = (min_tract_size ? total / 2 : total) + 2;
-  rec = (tjamd_located_record *) malloc ((size_t) cap * sizeof (tjamd_located_record));
   dev = tj_scratch_counter (kmer_size);
   n = tjamd_scan_host_located (dev, stream, (size_t) total, min_tract_size, rec, cap);
-  if (n > capacity) n = -1;
+  if (n > capacity) {
+    char msg[160];
+    snprintf (msg, sizeof msg, "tjamd_scan_windows: %ld tract records, caller capacity %ld", n, capacity);
+    tj_set_last_error (msg);
+    n = -1;
+  }
   for (i = 0; i < n; i++) {
     hopo_element *e = out + i;
     while ((long) rec[i].pos >= start[w + 1]) w++;      /* records come sorted by position */

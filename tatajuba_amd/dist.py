@@ -65,21 +65,3 @@ def merge_histograms_device(counter, records_u8, counts):
     if got < 0:
         raise TatajubaAmdError(_err())
     return keys[: got * RECORD_BYTES], mat[:got]
-
-
-def merge_histograms_host(records_u8, counts):
-    """Context-keyed union of the samples' histograms on the host (numpy; small: 1e5-1e6 records per sample).
-    Key = (base, ctx0, ctx1, length) in the reference's descending order; returns (keys structured array, int32 matrix
-    [n_union, n_samples] of per-sample depths).  Precursor of the location-keyed merge of src/genome_set.c:250-289,
-    which needs the (out-of-scope) BWA locations."""
-    from .capi import RECORD_DTYPE, decode_meta
-    rec = np.frombuffer(records_u8.tobytes() if not isinstance(records_u8, (bytes, bytearray)) else records_u8, dtype=RECORD_DTYPE)
-    sample = np.repeat(np.arange(len(counts)), counts)
-    d = decode_meta(rec["meta"])
-    key = np.zeros(len(rec), dtype=[("base", "i8"), ("ctx0", "u8"), ("ctx1", "u8"), ("length", "i8")])
-    key["base"], key["ctx0"], key["ctx1"], key["length"] = d["base"], rec["ctx0"], rec["ctx1"], d["length"]
-    uniq, inv = np.unique(key, return_inverse=True)
-    uniq, inv = uniq[::-1], (len(uniq) - 1 - inv)          # descending
-    mat = np.zeros((len(uniq), len(counts)), dtype=np.int32)
-    np.add.at(mat, (inv, sample), d["count"].astype(np.int32))
-    return uniq, mat

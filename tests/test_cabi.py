@@ -521,3 +521,77 @@ def test_oracle_grouping_by_hand():
     rec[:, 0] = [9, 9, 9, 7, 7]; rec[:, 1] = [4, 4, 3, 3, 3]; rec[:, 2] = [1, 1, 1, 1, 0]
     ids, n = orc.tract_ids(rec)
     assert ids.tolist() == [0, 0, 1, 2, 3] and n == 4
+
+
+def test_oracle_context_histograms_by_hand():
+    """new_genomic_context_list restated with the indel retry and the length histograms (oracle/context_oracle.c; reference:
+    src/context_histogram.c:19-23,245-286).  By hand, k = 4, names `left.A.right`:
+      e0 TTTT|GGGG x5 len 4     opens histogram 0
+      e1 TTTT|GGGG x9 len 3     same context: joins (idx_match 0), becomes the modal element
+      e2 TTTT|GGGC x4 len 4     one substitution: joins at max_distance 2, a second context
+      e3 TTTT|GCGG x7 len 4     2 substitutions from e2's context: fails the flank test; edit distance to the modal name
+                                TTTT.A.GGGG is 1 -> joins through the retry when levenshtein_distance >= 2, third context
+      e4 TTTT|CGGG x2 len 5     2 from e3's context -> fails; edit distance to TTTT.A.GGGG = 1 -> retry
+      e5 AAAA|AAAA x3 len 4     far from everything: opens histogram 1
+    UNPINNED: the edit distance itself (biomcmc-lib is absent) -- only its use is the reference's."""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    pack = lambda s: sum(code[ch] << (2 * i) for i, ch in enumerate(s))
+    rows = [("TTTT", "GGGG", 5, 4), ("TTTT", "GGGG", 9, 3), ("TTTT", "GGGC", 4, 4), ("TTTT", "GCGG", 7, 4), ("TTTT", "CGGG", 2, 5), ("AAAA", "AAAA", 3, 4)]
+    e = np.zeros(len(rows), dtype=tj.ELEM_DTYPE)
+    for i, (l, r, c, ln) in enumerate(rows):
+        e["ctx0"][i], e["ctx1"][i] = pack(l), pack(r)
+        e["meta"][i] = (ln << 2) | (c << 12)
+    e["read_offset"] = -1
+    assert orc.levenshtein("kitten", "sitting") == 3 and orc.levenshtein("TTTT.A.GCGG", "TTTT.A.GGGG") == 1 and orc.levenshtein("ACGT", "CGTA") == 2
+    r = orc.genomic_context_list(e, 4, 2, 2, 3)
+    assert r["group_of"].tolist() == [0, 0, 0, 0, 0, 1] and r["join_type"].tolist() == [0, 1, 1, 2, 2, 0]
+    g = r["groups"]
+    assert g["n_elem"].tolist() == [5, 1] and g["n_context"].tolist() == [4, 1] and g["indel"].tolist() == [1, 0]
+    assert g["mode"].tolist() == [1, 5] and g["mode_context_id"].tolist() == [0, 0] and g["mode_context_length"].tolist() == [3, 4]
+    assert g["integral"].tolist() == [27, 3]
+    # lengths of histogram 0: 4 -> 5 + 4 + 7 = 16, 3 -> 9, 5 -> 2; highest count first
+    assert g["n_len"].tolist() == [3, 1] and r["hist_len"][:3].tolist() == [4, 3, 5] and r["hist_freq"][:3].tolist() == [16, 9, 2]
+    assert g["modal_len"].tolist() == [4, 4] and g["modal_freq"].tolist() == [16, 3]
+    assert r["contexts"][:4].tolist() == [[pack("TTTT"), pack("GGGG")], [pack("TTTT"), pack("GGGC")], [pack("TTTT"), pack("GCGG")], [pack("TTTT"), pack("CGGG")]]
+    # the retry off (levenshtein_distance 0 can never be undercut): e3 opens a histogram, e4 is 2 away from e3 -> another one
+    r0 = orc.genomic_context_list(e, 4, 2, 0, 3)
+    assert r0["group_of"].tolist() == [0, 0, 0, 1, 2, 3] and r0["groups"]["indel"].sum() == 0
+    gof, first, nel, nctx, integ, mode = orc.group_contexts(e, 2)      # round 2's restatement of the flank test alone agrees
+    assert gof.tolist() == r0["group_of"].tolist() and nctx.tolist() == r0["groups"]["n_context"].tolist()
+
+
+def test_oracle_merge_order_by_hand():
+    """the cross-sample merge order restated (oracle/context_oracle.c; reference: src/genome_set.c:250-289, on a tie the
+    new genome's entry goes first :278-281), context-keyed: descending (base, ctx0, ctx1, signed length)"""
+    def rec(c0, c1, base, ln, cnt, flag=3):
+        return [c0, c1, base | ((ln & 0x3ff) << 2) | (cnt << 12) | (0xffe << 32) | (flag << 49)]
+    s0 = [rec(9, 4, 1, 5, 10), rec(9, 4, 1, 3, 2), rec(7, 1, 0, 4, 6)]
+    s1 = [rec(9, 4, 1, 5, 7, flag=1), rec(8, 8, 1, 4, 3), rec(7, 1, 0, 4, 1)]
+    s2 = [rec(9, 9, 1, 2, 5), rec(7, 1, 0, 4, 8)]
+    allr = np.array(s0 + s1 + s2, dtype=np.uint64)
+    cs, ci, keys, mat = orc.merge_samples(allr, [3, 3, 2])
+    # concatenated list: (sample, index), equal keys with the later sample first
+    assert list(zip(cs.tolist(), ci.tolist())) == [(2, 0), (1, 0), (0, 0), (0, 1), (1, 1), (2, 1), (1, 2), (0, 2)]
+    assert keys[:, 0].tolist() == [9, 9, 9, 8, 7] and keys[:, 1].tolist() == [9, 4, 4, 8, 1]
+    assert mat.tolist() == [[0, 0, 5], [10, 7, 0], [2, 0, 0], [0, 3, 0], [6, 1, 8]]
+    d = orc.decode_meta(keys[:, 2])
+    assert d["count"].tolist() == [5, 17, 2, 3, 15] and d["canon_flag"].tolist() == [3, 3, 3, 3, 3] and d["length"].tolist() == [2, 5, 3, 4, 4]
+
+
+def test_rccl_exchange_entry_points_check_their_arguments_without_a_gpu():
+    """the process-per-GPU exchange lives in the C library (ncclAllGather behind tjamd_allgather_histograms): the library
+    links RCCL, exports the entry points and refuses bad arguments before touching a device"""
+    import subprocess
+    L = tj.lib()
+    out = subprocess.run(["readelf", "-d", tj.library_path()], capture_output=True, text=True).stdout
+    assert "librccl.so" in out
+    assert L.tjamd_comm_unique_id(None) != 0 and b"null buffer" in L.tjamd_last_error()
+    ident = C.create_string_buffer(128)
+    assert L.tjamd_comm_create(None, ident, 0, 1) is None and b"bad arguments" in L.tjamd_last_error()
+    cnt = (C.c_long * 2)()
+    ptr = C.c_void_p()
+    assert L.tjamd_allgather_histograms(None, None, C.byref(ptr), cnt) < 0 and b"bad arguments" in L.tjamd_last_error()
+    assert L.tjamd_comm_rank(None) == -1 and L.tjamd_comm_world(None) == -1 and L.tjamd_comm_collectives(None) == -1
+    L.tjamd_comm_destroy(None)
+    buf = C.create_string_buffer(64)
+    assert L.tjamd_peer_access_report(buf, 64) == 0 and buf.value == b""

@@ -1,5 +1,6 @@
-"""The N > 1 path on CPU: two gloo ranks, one sample each, all-gatherv of the per-sample histograms and the
-context-keyed merge (tatajuba_amd/dist.py).  The histograms come from the CPU oracle here (no GPU in this test); the
+"""The N > 1 path on CPU: two gloo ranks, one sample each, all-gatherv of the per-sample histograms (tatajuba_amd/dist.py)
+and the context-keyed merge -- on the CPU that is the oracle's restatement of src/genome_set.c:250-289
+(oracle/context_oracle.c); the product's merge is a device kernel (tjamd_merge_samples).  The histograms come from the CPU oracle here (no GPU in this test); the
 GPU version of the same exchange runs in bench.py --gpus N and in tests/test_gpu_parity.py::test_merge_samples_device."""
 import os
 import socket
@@ -12,7 +13,7 @@ import torch.multiprocessing as mp
 
 import tatajuba_amd as tj
 from oracle import orc
-from tatajuba_amd.dist import all_gatherv_bytes, merge_histograms_host, RECORD_BYTES
+from tatajuba_amd.dist import all_gatherv_bytes, RECORD_BYTES
 
 
 def _sample_records(rank):
@@ -37,7 +38,7 @@ def _worker(rank, world, port, q):
     assert sizes[rank] == mine.nbytes and all(s % RECORD_BYTES == 0 for s in sizes)
     allrec = torch.cat(parts).numpy()
     counts = [s // RECORD_BYTES for s in sizes]
-    keys, mat = merge_histograms_host(allrec, counts)
+    _, _, keys, mat = orc.merge_samples(np.frombuffer(allrec.tobytes(), dtype=np.uint64).reshape(-1, 3), counts)
     # every rank computes the same union
     digest = torch.tensor([int(mat.astype(np.int64).sum()), len(keys)], dtype=torch.int64)
     gathered = [torch.zeros_like(digest) for _ in range(world)]
@@ -74,17 +75,19 @@ def test_two_rank_gather_and_merge():
     assert n_union == len(allkeys) and max_share == 2                         # the two samples share tracts
 
 
-def test_merge_host_order_and_counts():
+def test_merge_oracle_order_and_counts():
     a, b = _sample_records(0), _sample_records(1)
-    rec = np.concatenate([a, b]).view(np.uint8)
-    keys, mat = merge_histograms_host(rec, [len(a), len(b)])
-    k = np.stack([keys["base"].astype(np.int64), keys["ctx0"].astype(np.int64), keys["ctx1"].astype(np.int64)], 1)
-    tup = list(zip(keys["base"].tolist(), keys["ctx0"].tolist(), keys["ctx1"].tolist(), keys["length"].tolist()))
+    rec = np.frombuffer(np.concatenate([a, b]).tobytes(), dtype=np.uint64).reshape(-1, 3)
+    cs, ci, keys, mat = orc.merge_samples(rec, [len(a), len(b)])
+    d = tj.decode_meta(keys[:, 2])
+    tup = list(zip(d["base"].tolist(), keys[:, 0].tolist(), keys[:, 1].tolist(), d["length"].tolist()))
     assert all(tup[i] > tup[i + 1] for i in range(len(tup) - 1))              # reference's descending order, no duplicates
     da = tj.decode_meta(a["meta"])
     first = (int(da["base"][0]), int(a["ctx0"][0]), int(a["ctx1"][0]), int(da["length"][0]))
     assert mat[tup.index(first), 0] == da["count"][0]
     assert mat.shape == (len(tup), 2) and (mat >= 0).all() and (mat.sum(axis=1) > 0).all()
+    # the concatenated list keeps every record once, each sample's records in their own order
+    assert len(cs) == len(a) + len(b) and (ci[cs == 0] == np.arange(len(a))).all() and (ci[cs == 1] == np.arange(len(b))).all()
 
 
 def test_bench_launches_its_own_ranks():

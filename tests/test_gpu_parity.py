@@ -336,8 +336,13 @@ def test_finalise_in_two_calls_with_two_counters_on_one_stream(monkeypatch, mode
     streams = [tj.synth_stream(15000 + 3000 * i, 150, 80000, seed_reads=77 + i) for i in range(4)] + [np.frombuffer(b"ACGT\n", np.uint8)]
     devs = [torch.from_numpy(s.copy()).cuda() for s in streams]
     ctr = [tj.Counter(10), tj.Counter(10)]
+    # a stream of torch's making, as bench.py does: the current stream's handle is null, which tjamd_counter_set_stream reads
+    # as "the counter's own stream" -- two counters on ONE non-null stream is the configuration the headline bench runs
+    shared = torch.cuda.Stream()
+    assert shared.cuda_stream != 0
+    torch.cuda.synchronize()                                # (the uploads above went through the default stream)
     for c in ctr:
-        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.set_stream(shared.cuda_stream)
     begun, got = None, []
 
     def end(i):
@@ -363,6 +368,14 @@ def test_finalise_in_two_calls_with_two_counters_on_one_stream(monkeypatch, mode
         if st == 0:
             assert kept == o.elems().tobytes() and cov == o.c.coverage, i
     assert got[-1][1] == 1                                  # (the stream without a tract: the reference's "empty sample")
+    # the index ranges of the last full sample, through the same two-call path
+    c = ctr[0]
+    c.reset(); c.scan_device(devs[2].data_ptr(), streams[2].size, 3); c.finalise_begin(1, 3)
+    ctr[1].reset(); ctr[1].scan_device(devs[3].data_ptr(), streams[3].size, 3); ctr[1].finalise_begin(1, 3)
+    assert c.finalise_end() == 0 and ctr[1].finalise_end() == 0
+    o = orc.Oracle(10); o.scan_stream(streams[2], 3); o.finalise(1, 3)
+    gi, gf = c.download_idx(); ei, ef = o.idx()
+    assert (gi == ei).all() and (gf == ef).all() and c.download_kept().tobytes() == o.elems().tobytes()
     with pytest.raises(Exception):
         ctr[0].finalise_end()                               # nothing begun
     for c in ctr:
@@ -643,16 +656,18 @@ def test_many_small_batches_grow_the_bucket_storage(k, m):
 
 @pytest.mark.parametrize("k,n_samples,force_radix", [(15, 3, False), (15, 3, True), (10, 8, False), (25, 5, False), (32, 2, False), (2, 4, False)])
 def test_merge_samples_device(monkeypatch, k, n_samples, force_radix):
-    """cross-sample merge on the GPU == the numpy union (tatajuba_amd/dist.py), counts per sample and key order; the
-    bin path and (forced through the test hook) the radix path"""
+    """cross-sample merge on the GPU == the oracle's restatement of the reference's merge order (oracle/context_oracle.c;
+    src/genome_set.c:250-289, ties :278-281) collapsed into a union: keys, key order, the whole meta word (canon flag of the
+    first sample that has the key, count = total) and the counts per sample; the bin path and (forced through the test
+    hook) the radix path"""
     torch = pytest.importorskip("torch")
-    from tatajuba_amd.dist import merge_histograms_device, merge_histograms_host, device_bytes_tensor
+    from tatajuba_amd.dist import merge_histograms_device, device_bytes_tensor
     parts, counts, counters = [], [], []
     for smp in range(n_samples):
         s = tj.synth_stream(30000, 150, 200000, seed_reads=0x7A7A1000 + smp, variant_seed=smp)
         c = tj.Counter(k)
         c.scan_host(s, 4 if k > 2 else 1)
-        assert c.finalise(1, 0) == 0
+        assert c.finalise(smp % 2, 0) == 0                 # (every other sample keeps one-strand tracts: canon flags 1 and 2 in the union)
         counters.append(c)
         counts.append(c.n_kept)
         parts.append(device_bytes_tensor(c.kept_device_ptr, c.n_kept * 24, torch.device("cuda", 0)).clone())
@@ -661,14 +676,12 @@ def test_merge_samples_device(monkeypatch, k, n_samples, force_radix):
         monkeypatch.setenv("TATAJUBA_AMD_BIN_MAX", "1")
     merger = tj.Counter(k)
     keys_d, mat_d = merge_histograms_device(merger, rec, counts)
-    keys_h, mat_h = merge_histograms_host(rec.cpu().numpy(), counts)
-    kd = np.frombuffer(keys_d.cpu().numpy().tobytes(), dtype=tj.RECORD_DTYPE)
-    dd = tj.decode_meta(kd["meta"])
-    assert len(kd) == len(keys_h) > 0
-    assert (kd["ctx0"] == keys_h["ctx0"]).all() and (kd["ctx1"] == keys_h["ctx1"]).all()
-    assert (dd["base"] == keys_h["base"]).all() and (dd["length"] == keys_h["length"]).all()
-    assert (mat_d.cpu().numpy() == mat_h).all()
-    assert (dd["count"] == mat_h.sum(axis=1)).all()
+    _, _, keys_o, mat_o = orc.merge_samples(np.frombuffer(rec.cpu().numpy().tobytes(), dtype=np.uint64).reshape(-1, 3), counts)
+    kd = np.frombuffer(keys_d.cpu().numpy().tobytes(), dtype=np.uint64).reshape(-1, 3)
+    assert len(kd) == len(keys_o) > 0
+    assert (kd == keys_o).all()
+    assert (mat_d.cpu().numpy() == mat_o).all()
+    assert (tj.decode_meta(kd[:, 2])["count"] == mat_o.sum(axis=1)).all()
     # twice through the same merger (its buffers and counters are reused)
     keys_2, mat_2 = merge_histograms_device(merger, rec, counts)
     assert torch.equal(keys_2, keys_d) and torch.equal(mat_2, mat_d)
@@ -860,12 +873,80 @@ def test_group_contexts_matches_the_oracle(k, maxd):
     c.close()
 
 
+def _hist_mask(groups, n):
+    m = np.zeros(n, bool)
+    for f, nl in zip(groups["first"], groups["n_len"]):
+        m[f:f + nl] = True
+    return m
+
+
+@pytest.mark.parametrize("k,maxd,lev", [(10, 1, 2), (10, 1, 3), (10, 2, 3), (10, 0, 2), (10, 2, 0), (25, 2, 4), (32, 1, 3), (4, 1, 2)])
+def test_context_histograms_with_indel_retry_match_the_oracle(k, maxd, lev):
+    """tjamd_context_histograms == the oracle's restatement of new_genomic_context_list (src/context_histogram.c:245-270: flank
+    distance :25-48, then the retry with the edit distance between the names :19-23,255-261, bookkeeping :181-222, length
+    histograms :278-286) on a sample whose families differ by substitutions AND by one-base indels in the right flank (the
+    left flank's first bases vary as well: in context order those stay neighbours).  UNPINNED pieces, same on both sides:
+    the edit distance (biomcmc_levenshtein_distance is absent from the reference tree: unit-cost global edit distance) and
+    the order of equal counts in a length histogram."""
+    rng = random.Random(1000 * k + 10 * maxd + lev)
+    mask = (1 << (2 * k)) - 1
+    e = []
+    for fam in range(2500):
+        c0, c1, base = rng.getrandbits(2 * k) & mask, rng.getrandbits(2 * k) & mask, rng.randrange(2)
+        for member in range(rng.choice([1, 1, 2, 3, 5, 8])):
+            a, b = c0, c1
+            for _ in range(rng.choice([0, 1, 1, 2, 3])):
+                r = rng.random()
+                if r < 0.25:
+                    a ^= rng.randrange(1, 4) << (2 * rng.randrange(min(k, 2)))        # first bases of the left flank
+                elif r < 0.5:
+                    b ^= rng.randrange(1, 4) << (2 * rng.randrange(k))                # substitution in the right flank
+                elif r < 0.75:
+                    p = rng.randrange(k)                                              # insertion in the right flank at base p
+                    lo = b & ((1 << (2 * p)) - 1)
+                    b = (lo | (rng.randrange(4) << (2 * p)) | ((b >> (2 * p)) << (2 * p + 2))) & mask
+                else:
+                    p = rng.randrange(k)                                              # deletion at base p, a new last base
+                    lo = b & ((1 << (2 * p)) - 1)
+                    b = (lo | ((b >> (2 * p + 2)) << (2 * p)) | (rng.randrange(4) << (2 * k - 2))) & mask
+            for length in rng.sample(range(3, 12), rng.choice([1, 2, 3])):
+                e += [(a, b, base, length)] * rng.randrange(2, 9)
+    raw = np.zeros(len(e), dtype=tj.ELEM_DTYPE)
+    for i, (a, b, base, length) in enumerate(e):
+        raw["ctx0"][i], raw["ctx1"][i] = a, b
+        raw["meta"][i] = base | (length << 2) | (1 << 12) | (0xffe << 32) | (1 << 49)
+    raw["read_offset"] = 0; raw["loc_ref_id"] = raw["loc_pos"] = raw["loc_last"] = -1
+    c = tj.Counter(k)
+    c.upload_raw(raw)
+    assert c.finalise(0, 0) == 0
+    kept = c.download_kept()
+    got = c.context_histograms(maxd, lev)
+    want = orc.genomic_context_list(kept, k, maxd, lev, 3)
+    g, w = got["groups"], want["groups"]
+    assert len(g) == len(w) and (got["group_of"] == want["group_of"]).all() and (got["join_type"] == want["join_type"]).all()
+    for f in ("first", "n_elem", "n_context", "mode", "indel", "n_len", "modal_len", "modal_freq", "integral"):
+        assert (g[f] == w[f]).all(), f
+    m = _hist_mask(w, len(kept))
+    assert (got["hist"]["length"][m] == want["hist_len"][m]).all() and (got["hist"]["freq"][m] == want["hist_freq"][m]).all()
+    # what the modal element says about its histogram (reference: src/context_histogram.c:192-196)
+    meta = tj.decode_meta(kept["meta"])
+    assert (meta["count"][g["mode"]] == w["mode_context_count"]).all() and (meta["length"][g["mode"]] == w["mode_context_length"]).all()
+    if lev > 1 and maxd > 0:
+        assert (want["join_type"] == 2).sum() > 0 and g["indel"].sum() > 0            # the retry took elements in ...
+        ham_only = c.group_contexts(maxd)[1]
+        assert len(g) < len(ham_only)                                                 # ... that the flank distance alone leaves out
+    if lev == 0:
+        gof0, grp0 = c.group_contexts(maxd)                                           # without a retry: the round-2 entry's groups
+        assert (gof0 == got["group_of"]).all() and (grp0["n_context"] == g["n_context"]).all() and g["indel"].sum() == 0
+    c.close()
+
+
 def test_tract_ids_and_in_process_gather():
     """tjamd_gather_histograms (the exchange for samples that are threads of one process, as in the reference) followed by
-    tjamd_merge_samples == the python-side exchange; tjamd_tract_ids == the oracle's id pass over the union"""
+    tjamd_merge_samples == the oracle's merge (src/genome_set.c:250-289 restated); tjamd_tract_ids == the oracle's id pass over the union"""
     torch = pytest.importorskip("torch")
     import ctypes as C
-    from tatajuba_amd.dist import merge_histograms_host, device_bytes_tensor
+    from tatajuba_amd.dist import device_bytes_tensor
     k, counters = 10, []
     for smp in range(3):
         s = tj.synth_stream(30000, 150, 200000, seed_reads=0x7A7A1000 + smp, variant_seed=smp)
@@ -884,8 +965,9 @@ def test_tract_ids_and_in_process_gather():
     keys = torch.empty(total * 24, dtype=torch.uint8, device="cuda")
     mat = torch.empty((total, 3), dtype=torch.int32, device="cuda")
     nu = L.tjamd_merge_samples(counters[0]._h, drec, counts, 3, C.c_void_p(keys.data_ptr()), C.c_void_p(mat.data_ptr()), total)
-    keys_h, mat_h = merge_histograms_host(rec, list(counts))
-    assert nu == len(keys_h) and (mat[:nu].cpu().numpy() == mat_h).all()
+    _, _, keys_o, mat_o = orc.merge_samples(np.frombuffer(rec.tobytes(), dtype=np.uint64).reshape(-1, 3), list(counts))
+    assert nu == len(keys_o) and (mat[:nu].cpu().numpy() == mat_o).all()
+    assert (np.frombuffer(keys[: nu * 24].cpu().numpy().tobytes(), dtype=np.uint64).reshape(-1, 3) == keys_o).all()
     ids = np.zeros(nu, np.int32)
     nid = L.tjamd_tract_ids(counters[0]._h, C.c_void_p(keys.data_ptr()), nu, None, ids.ctypes.data)
     kd = np.frombuffer(keys[: nu * 24].cpu().numpy().tobytes(), dtype=np.uint64).reshape(-1, 3)
@@ -893,6 +975,101 @@ def test_tract_ids_and_in_process_gather():
     assert nid == onid and (ids == oids).all() and 0 < nid < nu
     for c in counters:
         c.close()
+
+
+def test_config4_pipeline_eight_samples_end_to_end():
+    """BASELINE.json configs[3] as ONE pipeline at reduced size (8 samples of the same genome with per-sample tract-length
+    variants, 150 bp reads of both strands, k = 15, min_tract = 4, remove_biased = 1): scan -> finalise on eight counters of
+    one GPU -> tjamd_gather_histograms -> tjamd_merge_samples -> tjamd_tract_ids, every stage against the oracle
+    (reference: src/genome_set.c:66-94 per-sample loop, :195-229 and :250-289 merge, :207-221 tract ids)."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from tatajuba_amd.dist import device_bytes_tensor
+    k, m, ns = 15, 4, 8
+    counters, okept = [], []
+    for smp in range(ns):
+        s = tj.synth_stream(150000, 150, 1000000, seed_reads=0x7A7A1000 + smp, variant_seed=smp)
+        c = tj.Counter(k)
+        c.scan_host(s, m)
+        o = orc.Oracle(k)
+        o.scan_stream(s, m)
+        assert c.raw_count() == o.c.n_elem
+        st = c.finalise(1, 5)
+        o.finalise(1, 5)
+        assert st == o.c.status == 0
+        assert c.download_kept().tobytes() == o.elems().tobytes()
+        gi, gf = c.download_idx()
+        ei, ef = o.idx()
+        assert (gi == ei).all() and (gf == ef).all() and c.coverage == o.c.coverage
+        counters.append(c)
+        okept.append(as_records(o.elems()))
+        o.close()
+    L = tj.lib()
+    hs = (C.c_void_p * ns)(*[c._h for c in counters])
+    drec, counts = C.c_void_p(), (C.c_long * ns)()
+    merger = tj.Counter(k)
+    total = L.tjamd_gather_histograms(merger._h, hs, ns, C.byref(drec), counts)
+    assert total == sum(len(x) for x in okept) and list(counts) == [len(x) for x in okept]
+    rec = device_bytes_tensor(drec.value, total * 24, torch.device("cuda", 0)).cpu().numpy()
+    want = np.concatenate(okept)
+    assert rec.tobytes() == want.tobytes()
+    keys = torch.empty(total * 24, dtype=torch.uint8, device="cuda")
+    mat = torch.empty((total, ns), dtype=torch.int32, device="cuda")
+    nu = L.tjamd_merge_samples(merger._h, drec, counts, ns, C.c_void_p(keys.data_ptr()), C.c_void_p(mat.data_ptr()), total)
+    _, _, keys_o, mat_o = orc.merge_samples(np.frombuffer(want.tobytes(), dtype=np.uint64).reshape(-1, 3), list(counts))
+    kd = np.frombuffer(keys[: nu * 24].cpu().numpy().tobytes(), dtype=np.uint64).reshape(-1, 3)
+    assert nu == len(keys_o) and (kd == keys_o).all() and (mat[:nu].cpu().numpy() == mat_o).all()
+    ids = np.zeros(nu, np.int32)
+    nid = L.tjamd_tract_ids(merger._h, C.c_void_p(keys.data_ptr()), nu, None, ids.ctypes.data)
+    oids, onid = orc.tract_ids(kd)
+    assert nid == onid and (ids == oids).all() and 0 < nid < nu
+    # the samples differ (variants) and share most tracts
+    share = (mat_o > 0).sum(axis=1)
+    assert share.max() == ns and share.min() >= 1 and (share < ns).any()
+    merger.close()
+    for c in counters:
+        c.close()
+
+
+def test_rccl_allgather_of_one_rank_and_block_size_protocol():
+    """tjamd_allgather_histograms (ncclAllGather behind the C ABI) on a communicator of one rank -- all a one-GPU box can run:
+    the gathered buffer is the counter's kept records, the first exchange learns the counts first (two collectives), the
+    next one sends one block, a sample that outgrows the agreed block size is exchanged again at the right size.  The
+    multi-rank path is the same code with world > 1; it has not run on more than one device."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from tatajuba_amd.dist import device_bytes_tensor
+    L = tj.lib()
+    k = 10
+    small = tj.Counter(k)
+    small.scan_host(tj.synth_stream(20000, 150, 100000, seed_reads=0x7A7A1000), 3)
+    assert small.finalise(1, 0) == 0
+    big = tj.Counter(k)
+    big.scan_host(tj.synth_stream(400000, 150, 2000000, seed_reads=0x7A7A1001, variant_seed=1), 3)
+    assert big.finalise(0, 0) == 0 and big.n_kept > 2 * small.n_kept + 8192
+    ident = C.create_string_buffer(128)
+    assert L.tjamd_comm_unique_id(ident) == 0
+    comm = L.tjamd_comm_create(small._h, ident, 0, 1)
+    assert comm, L.tjamd_last_error()
+    assert L.tjamd_comm_rank(comm) == 0 and L.tjamd_comm_world(comm) == 1
+
+    def exchange(c):
+        ptr, cnt = C.c_void_p(), (C.c_long * 1)()
+        tot = L.tjamd_allgather_histograms(c._h, comm, C.byref(ptr), cnt)
+        assert tot == c.n_kept == cnt[0], L.tjamd_last_error()
+        got = device_bytes_tensor(ptr.value, tot * 24, torch.device("cuda", 0)).cpu().numpy()
+        assert got.tobytes() == as_records(c.download_kept()).tobytes()
+
+    exchange(small)
+    assert L.tjamd_comm_collectives(comm) == 2                 # counts, then the block
+    exchange(small)
+    assert L.tjamd_comm_collectives(comm) == 3                 # the block size is agreed: one collective
+    exchange(big)                                              # does not fit the agreed block: one wasted, then counts + block
+    assert L.tjamd_comm_collectives(comm) == 6
+    exchange(big)
+    assert L.tjamd_comm_collectives(comm) == 7
+    L.tjamd_comm_destroy(comm)
+    small.close(); big.close()
 
 
 def test_merge_samples_c_example(tmp_path):
