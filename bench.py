@@ -475,6 +475,26 @@ def main():
                    "finalise": {"ms": fin_avg, "algorithmic_GBps": fin_gbs, "frac_of_hbm_peak": fin_gbs / HBM_PEAK_GBS}},
     }
 
+    if rank == 0 and world == 1:
+        # what a C caller of the drop-in API gets per sample once its reads are in HBM: the scan, the whole of
+        # finalise_hopo_counter's device work AND the copy of the histogram into hc->elem (24-byte records widened to the
+        # 40-byte hopo_element on the host) + the index arrays -- the part of finalise_hopo_counter (csrc/hopo_host.c) that a
+        # bench step, which leaves the histogram in HBM, does not pay.  One counter, synchronous calls, best of five.
+        cd = tj.Counter(k, device=local)
+        best = 1e9
+        for rep in range(5):
+            cd.reset()
+            t1 = time.perf_counter()
+            cd.scan_device(dev.data_ptr(), n_bytes, m)
+            if cd.finalise(1, args.min_coverage) != 0:
+                raise SystemExit("finalise failed in the drop-in stage")
+            elems = cd.download_kept()
+            cd.download_idx()
+            best = min(best, time.perf_counter() - t1)
+        out["stages"]["dropin"] = {"ms": best * 1e3, "reads_per_s": args.reads / best, "kept_records": int(len(elems)),
+                                   "note": "HBM-resident stream -> scan + finalise + histogram copied into 40-byte hopo_elements on the host "
+                                           "+ index arrays (what finalise_hopo_counter hands a C caller), synchronous, one counter"}
+        cd.close()
     if rank == 0 and world == 1 and not args.no_io_stages:
         out["stages"].update(io_stages(tj, host, args, k, m, L))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

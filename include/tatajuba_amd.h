@@ -200,6 +200,9 @@ void tjamd_thread_cleanup (void);
 double tjamd_last_scan_ms (tjamd_counter *c);       /* scan kernel(s) of the last tjamd_scan_* call */
 double tjamd_last_finalise_ms (tjamd_counter *c);   /* whole device finalise of the last tjamd_finalise call */
 long   tjamd_last_scan_launches (tjamd_counter *c);
+/* finalises of this counter whose device-side sizing of the ordering step had read a stale kept count (checked against the
+ * count at the next kernel boundary and repaired; expected to stay 0) */
+long   tjamd_plan_mismatches (tjamd_counter *c);
 
 /* synthetic inputs: genome of `genome_len` i.i.d. bases from splitmix64(seed_genome); n_reads reads of
  * length read_len (or uniform in [read_len, read_len_max] when read_len_max > read_len), uniform start, strand by coin,

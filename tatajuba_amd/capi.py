@@ -90,8 +90,11 @@ EXPORTS = [
     "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_finalise_begin", "tjamd_finalise_end", "tjamd_kept_count",
     "tjamd_n_idx", "tjamd_coverage", "tjamd_download_kept", "tjamd_download_idx", "tjamd_kept_device_ptr",
     "tjamd_merge_samples", "tjamd_gather_histograms", "tjamd_peer_access_report", "tjamd_comm_unique_id", "tjamd_comm_create", "tjamd_comm_destroy",
-    "tjamd_comm_set_stream", "tjamd_comm_rank", "tjamd_comm_world", "tjamd_comm_collectives", "tjamd_allgather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_context_histograms", "tjamd_scan_windows", "tjamd_thread_cleanup", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches",
+    "tjamd_comm_set_stream", "tjamd_comm_rank", "tjamd_comm_world", "tjamd_comm_collectives", "tjamd_allgather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_context_histograms", "tjamd_scan_windows", "tjamd_thread_cleanup", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches", "tjamd_plan_mismatches",
     "tjamd_synth_stream", "tjamd_read_file_stream",
+    # include/tatajuba_context.h
+    "new_genomic_context_list", "del_genomic_context_list", "del_context_histogram",
+    "distance_between_context_histogram_and_hopo_context", "indel_distance_between_context_histogram_and_hopo_context",
 ]
 
 
@@ -182,6 +185,8 @@ def lib():
     L.tjamd_tract_ids.restype = C.c_long; L.tjamd_tract_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
     L.tjamd_group_contexts.restype = C.c_long
     L.tjamd_group_contexts.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    L.new_genomic_context_list.restype = C.POINTER(GenomicContextListStruct); L.new_genomic_context_list.argtypes = [P]
+    L.del_genomic_context_list.restype = None; L.del_genomic_context_list.argtypes = [C.POINTER(GenomicContextListStruct)]
     L.tjamd_comm_unique_id.argtypes = [C.c_void_p]
     L.tjamd_comm_create.restype = C.c_void_p; L.tjamd_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.tjamd_comm_destroy.restype = None; L.tjamd_comm_destroy.argtypes = [C.c_void_p]
@@ -268,6 +273,29 @@ def read_file_stream(path):
     got = lib().tjamd_read_file_stream(os.fsencode(path), out.ctypes.data, need, C.byref(n))
     assert got == need
     return out[:need], n.value
+
+
+class EmpfreqElement(C.Structure):
+    _fields_ = [("freq", C.c_int), ("idx", C.c_int)]
+
+
+class EmpfreqStruct(C.Structure):
+    _fields_ = [("i", C.POINTER(EmpfreqElement)), ("n", C.c_int), ("min", C.c_int), ("max", C.c_int)]
+
+
+class ContextHistogramStruct(C.Structure):
+    """struct context_histogram_struct (include/tatajuba_context.h; reference src/context_histogram.h:18-43 without gffeature)"""
+    _fields_ = [("context", C.POINTER(C.c_uint64)),
+                ("base", C.c_int32, 2), ("multi", C.c_int32, 3), ("indel", C.c_int32, 2), ("neg_strand", C.c_int32, 1), ("mismatches", C.c_int32, 12),
+                ("name", C.c_char_p), ("n_context", C.c_int), ("integral", C.c_int), ("location", C.c_int), ("loc2d", C.c_int * 3),
+                ("coverage", C.c_int), ("n_tracts", C.c_int), ("mode_context_count", C.c_int), ("mode_context_length", C.c_int),
+                ("mode_context_id", C.c_int), ("tmp_count", C.POINTER(C.c_int)), ("tmp_length", C.POINTER(C.c_int)), ("index", C.c_int),
+                ("h", C.POINTER(EmpfreqStruct)), ("tract_id", C.c_int), ("ref_counter", C.c_int)]
+
+
+class GenomicContextListStruct(C.Structure):
+    _fields_ = [("hist", C.POINTER(C.POINTER(ContextHistogramStruct))), ("name", C.c_char_p), ("opt", Options),
+                ("n_hist", C.c_int), ("coverage", C.c_int), ("ref_start", C.c_int)]
 
 
 class Comm:
@@ -442,6 +470,11 @@ class Counter:
 
     def last_scan_launches(self):
         return int(lib().tjamd_last_scan_launches(self._h))
+
+    def plan_mismatches(self):
+        lib().tjamd_plan_mismatches.restype = C.c_long
+        lib().tjamd_plan_mismatches.argtypes = [C.c_void_p]
+        return int(lib().tjamd_plan_mismatches(self._h))
 
     def last_scan_ms(self):
         return lib().tjamd_last_scan_ms(self._h)

@@ -120,7 +120,7 @@ struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow, 
 // The sizes the ordering kernels work with, derived on the device from the number of kept records so that the host does
 // not have to fetch that number between the aggregation and them (plan_tail; ok = 0: nothing to do, or more records
 // than the buffers were sized for -- every kernel then returns at once and the host takes the exact path).
-struct FinPlan { long n1; long t; int nbits, nbins, log2t, ok; u32 kept_overflow, pad; };
+struct FinPlan { long n1; long t; int nbits, nbins, log2t, ok; u32 kept_overflow, pad; long n1_exact; u32 ovf_exact, pad2; };   // (n1_exact, ovf_exact: read at the kernel boundary after the aggregation, see clear_buckets_kernel)
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1593,8 +1593,14 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         // hold bytes with other low bits: they can never match; the second chance has 'N' at 6)
         const u32 rec = __builtin_amdgcn_perm (NP ? 0x474E0054u : 0x47000054u, 0x430A4101u, sel);
         bad = __builtin_amdgcn_bitop3_b32 (bad, w, rec, BITOP3_OR_XOR);
-        // 2-bit code = bits 1-2 of b ^ (b >> 1) (A 0, C 1, G 2, T 3; N 0), gathered 4 bytes -> 8 bits (twice the value: the codes sit at bit 1)
+        // 2-bit code (A 0, C 1, G 2, T 3; N 0; the delimiter 3, which no record ever packs) at bits 1-2 of every byte, gathered
+        // 4 bytes -> 8 bits (twice the value).  FK_CODE_LUT: by table look-up on the low three bits (one v_perm) instead of
+        // b ^ (b >> 1) masked (a shift and a v_bitop3): one instruction less per word
+#ifdef FK_CODE_LUT
+        const u32 cd = __builtin_amdgcn_perm (0x04000006u, 0x02060000u, sel);
+#else
         const u32 cd = __builtin_amdgcn_bitop3_b32 (w, M06, w >> 1, BITOP3_XOR_AND);
+#endif
         r[j] = __builtin_amdgcn_udot4 (cd, 0x40100401u, 0u, false);
         // letters have bit 6 ('\n' has not): 64 x the byte of 8 flags per pair of words
         const u32 wts = (j & 1) ? 0x80402010u : 0x08040201u;
@@ -1889,11 +1895,20 @@ __global__ void init_table_kernel (u32 *table, u32 maxj, u32 *pool_next)
 // One workgroup per bucket; only the row entries the bucket can have claimed are rewritten (its records / chunk + the
 // one claimed ahead), unless the whole row is asked for.
 __global__ void clear_buckets_kernel (u32 *cursors, DevCounters *ctr, u32 *table, u32 maxj, int ch_shift, FinCounts *fin, u32 *bins, int nbins,
-                                      DevCounters *snap_ctr, u32 *snap_cursors)
+                                      DevCounters *snap_ctr, u32 *snap_cursors, FinPlan *plan)
 {
   const u32 b = blockIdx.x;
   if (snap_ctr) {                                       // (every workgroup reads its own cursor, workgroup 0 the rest: before anything is zeroed)
-    if (threadIdx.x == 0) { snap_cursors[b] = cursors[b]; if (b == 0) snap_cursors[TJ_P] = cursors[TJ_P]; }
+    if (threadIdx.x == 0) {
+      snap_cursors[b] = cursors[b];
+      if (b == 0) {
+        snap_cursors[TJ_P] = cursors[TJ_P];
+        // The kept count and the overflow flag as a kernel boundary shows them.  plan_tail read them inside the
+        // aggregation, from its last workgroup, through relaxed atomics and no fence (a fence there doubled the kernel's
+        // time): the host compares the two readings and runs the ordering step again if they ever differ.
+        if (plan) { plan->n1_exact = (long) fin->n_kept; plan->ovf_exact = fin->overflow; }
+      }
+    }
     if (b == 0) for (u32 i = threadIdx.x; i < sizeof (DevCounters) / 4; i += blockDim.x) reinterpret_cast<u32 *> (snap_ctr)[i] = reinterpret_cast<const u32 *> (ctr)[i];
     __syncthreads ();
   }
@@ -3387,6 +3402,7 @@ struct tjamd_counter
   unsigned scan_seq = 0;
   size_t piece_target = TJ_SCAN_PIECE_TARGET;           // TATAJUBA_AMD_SCAN_PIECE (bytes) overrides it: tests
   bool buckets_clean = false;
+  long plan_mismatches = 0;   // finalises whose in-kernel reading of the kept count differed from the kernel boundary's (expected: 0)
   bool ctr_clean = false;     // the scan counters are zero but for n_undefined (clear_buckets_kernel did it, no scan since)
 };
 
@@ -3493,7 +3509,8 @@ static int clear_buckets (tjamd_counter *c, bool snapshot = false)
   if (!c->buckets_clean || snapshot) {
     hipLaunchKernelGGL (clear_buckets_kernel, dim3 (TJ_P), dim3 (256), 0, c->stream, c->d_cursors, c->d_ctr,
                         (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj, c->ch_shift, c->d_fin, (u32 *) c->bins.p, c->bins.p ? BS_MAXBINS : 0,
-                        snapshot ? &c->d_state->snap_ctr : (DevCounters *) nullptr, snapshot ? c->d_state->snap_cursors : (u32 *) nullptr);
+                        snapshot ? &c->d_state->snap_ctr : (DevCounters *) nullptr, snapshot ? c->d_state->snap_cursors : (u32 *) nullptr,
+                        snapshot ? &c->d_state->plan : (FinPlan *) nullptr);
     HIPCHK (hipGetLastError ());
     c->buckets_clean = true;
     c->ctr_clean = true;
@@ -4189,6 +4206,15 @@ second_half:
     if (n == 0) { c->status = 1; if (status) *status = 1; return TJAMD_OK; }                // reference: src/hopo_counter.c:345-349
     if (n >= (1l << 31)) return set_err (TJAMD_ERR_CAPACITY, "%ld raw records exceed the reference's int n_elem", n);
   }
+  if (plan_ahead) {
+    // what the aggregation's last workgroup read against what the kernel boundary behind it shows (the
+    // last-workgroup pattern has no fence); a difference is repaired by sizing the ordering step again, from the exact count
+    FinPlan &pl = c->h_state->plan;
+    if (pl.n1 != pl.n1_exact || pl.kept_overflow != pl.ovf_exact) {
+      c->plan_mismatches++;
+      pl.n1 = pl.n1_exact; pl.kept_overflow = pl.ovf_exact; pl.ok = 0;
+    }
+  }
   if (plan_ahead ? c->h_state->plan.kept_overflow : c->h_fin->overflow) return set_err (TJAMD_ERR_CAPACITY, "kept list overflow");
   const long n1 = plan_ahead ? c->h_state->plan.n1 : (long) c->h_fin->n_kept;
   if (n1 == 0) {                                                               // reference :376-381
@@ -4264,6 +4290,7 @@ extern "C" double tjamd_last_finalise_ms (tjamd_counter *c)
 }
 
 extern "C" long tjamd_last_scan_launches (tjamd_counter *c) { return c ? c->last_scan_launches : -1; }
+extern "C" long tjamd_plan_mismatches (tjamd_counter *c) { return c ? c->plan_mismatches : -1; }
 
 // radix path of the merge: tag, stable sort, run heads, scans (any size, any skew)
 static long merge_samples_radix (tjamd_counter *c, const void *d_records, long n, int n_samples, void *d_out_keys, void *d_out_counts, long capacity);

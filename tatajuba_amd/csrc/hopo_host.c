@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /* hopo_host.c -- C host side of the drop-in boundary (include/tatajuba_hopo.h).
  *
  * Same function names, argument meaning and error behaviour as tatajuba's src/hopo_counter.c for the per-read scan and
@@ -7,6 +8,7 @@
  */
 #include "../../include/tatajuba_amd.h"
 #include <pthread.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include "fastq_reader.h"
@@ -92,6 +94,9 @@ tj_device_counter (hopo_counter hc)
   }
   return pv->dev;
 }
+
+/* (context_host.c: the counter's device side, NULL if it never had one) */
+tjamd_counter *tj_counter_device (hopo_counter hc) { return hc ? tj_priv (hc)->dev : NULL; }
 
 /* ---- constructor / destructor (reference: src/hopo_counter.c:159-186) ---------------------------------------------- */
 
@@ -186,12 +191,40 @@ static int tj_sink_sync (void *ctx) { return tjamd_raw_count (((tj_gpu_sink *) c
 static long tj_sink_mark (void *ctx) { return tjamd_mark (((tj_gpu_sink *) ctx)->dev); }
 static int tj_sink_wait (void *ctx, long mark) { return tjamd_wait_mark (((tj_gpu_sink *) ctx)->dev, (int) mark); }
 
+/* CPUs this process may use: online processors, cut down to the affinity mask and to a cgroup CPU quota if there is one
+ * (a container given 16 of a host's 256 cores reports 256 online) */
+static long
+tj_cpu_budget (void)
+{
+  long n = sysconf (_SC_NPROCESSORS_ONLN);
+  cpu_set_t set;
+  FILE *f;
+  if (sched_getaffinity (0, sizeof set, &set) == 0) { const long a = CPU_COUNT (&set); if (a > 0 && a < n) n = a; }
+  f = fopen ("/sys/fs/cgroup/cpu.max", "r");            /* cgroup v2: "<quota> <period>" or "max <period>" */
+  if (f) {
+    long quota = 0, period = 0;
+    if (fscanf (f, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0) { const long q = (quota + period - 1) / period; if (q < n) n = q; }
+    fclose (f);
+  }
+  return n < 1 ? 1 : n;
+}
+
+static int tj_files_in_flight;                          /* new_or_append_hopo_counter_from_file calls that are parsing right now */
+
+/* Feeder threads of one file: the CPUs of the process shared among the files being read at this moment (the reference's
+ * caller runs one thread per sample, src/genome_set.c:66-68: eight samples at once get an eighth each, one sample alone
+ * gets them all), at most TJF_MAX_THREADS.  TATAJUBA_AMD_FEEDER_THREADS overrides. */
 static int
 tj_feeder_threads (void)
 {
   const char *e = getenv ("TATAJUBA_AMD_FEEDER_THREADS");
-  long n = e ? atol (e) : sysconf (_SC_NPROCESSORS_ONLN);
-  if (!e && n > 8) n = 8;                               /* the caller may already run one thread per sample */
+  long n;
+  if (e) n = atol (e);
+  else {
+    long active = __atomic_load_n (&tj_files_in_flight, __ATOMIC_RELAXED);
+    if (active < 1) active = 1;
+    n = tj_cpu_budget () / active;
+  }
   if (n < 1) n = 1;
   if (n > TJF_MAX_THREADS) n = TJF_MAX_THREADS;
   return (int) n;
@@ -225,7 +258,9 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
   if (h->idx_initial) tj_fatal ("This counter has been compared to another; cannot add more reads to it"); /* reference :152 */
   {                                                     /* big file: several readers / inflaters (feeder.c), same output */
     struct stat st;
-    const int threads = tj_feeder_threads ();
+    int threads;
+    (void) __atomic_add_fetch (&tj_files_in_flight, 1, __ATOMIC_RELAXED);
+    threads = tj_feeder_threads ();
     const int plain = threads > 1 ? tjf_is_plain_file (filename) : -1;
     if (plain >= 0 && stat (filename, &st) == 0 && st.st_size >= (plain ? TJ_FEEDER_MIN_BYTES : TJ_FEEDER_MIN_GZ_BYTES)) {
       tj_gpu_sink g;
@@ -245,9 +280,11 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
         if (n < 0) tj_fatal ("%s", tjamd_last_error ());
         tj_priv (h)->n_device = n;
         h->n_elem = tj_n_elem (tj_priv (h)->n_host, n, h->name);
+        (void) __atomic_sub_fetch (&tj_files_in_flight, 1, __ATOMIC_RELAXED);
         return h;
       }                                                 /* (-1: cannot open / map -- the one-reader path reports it) */
     }
+    (void) __atomic_sub_fetch (&tj_files_in_flight, 1, __ATOMIC_RELAXED);
   }
   rd = tjr_open (filename);
   if (!rd) tj_fatal ("cannot open '%s' (the reference leaves gzopen unchecked, src/hopo_counter.c:142; this build stops)", filename);

@@ -379,6 +379,7 @@ def test_finalise_in_two_calls_with_two_counters_on_one_stream(monkeypatch, mode
     with pytest.raises(Exception):
         ctr[0].finalise_end()                               # nothing begun
     for c in ctr:
+        assert c.plan_mismatches() == 0                     # (the in-kernel reading of the kept count agreed with the kernel boundary's every time)
         c.close()
 
 
@@ -939,6 +940,74 @@ def test_context_histograms_with_indel_retry_match_the_oracle(k, maxd, lev):
         gof0, grp0 = c.group_contexts(maxd)                                           # without a retry: the round-2 entry's groups
         assert (gof0 == got["group_of"]).all() and (grp0["n_context"] == g["n_context"]).all() and g["indel"].sum() == 0
     c.close()
+
+
+@pytest.mark.parametrize("k,maxd,lev", [(10, 1, 2), (8, 2, 3)])
+def test_new_genomic_context_list_drop_in(tmp_path, k, maxd, lev):
+    """new_genomic_context_list (include/tatajuba_context.h: finalise, then the reference's grouping loop with distances from the
+    device) on a FASTQ file of error-laden reads (substitutions and one-base indels, deep enough for the errors to recur) ==
+    the oracle's restatement of src/context_histogram.c:224-286, struct field by struct field: contexts in the order they
+    were added, modal context, name, indel flag, integral, the length histogram `h`."""
+    from tatajuba_amd.capi import Options
+    rng = random.Random(5 * k + lev)
+    genome = bytearray(rng.choice(b"ACGT") for _ in range(6000))
+    for _ in range(150):                                    # plant tracts
+        p, ln, b = rng.randrange(50, 5900), rng.randrange(3, 9), rng.choice(b"ACGT")
+        genome[p:p + ln] = bytes([b]) * ln
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for _ in range(40000):
+        p = rng.randrange(0, len(genome) - 100)
+        r = bytearray(genome[p:p + 100])
+        for _ in range(rng.choice([0, 0, 1, 1, 2])):        # sequencing errors
+            q, what = rng.randrange(len(r)), rng.random()
+            if what < 0.6:
+                r[q] = rng.choice(b"ACGT")
+            elif what < 0.8:
+                del r[q]
+            else:
+                r.insert(q, rng.choice(b"ACGT"))
+        r = bytes(r)
+        reads.append(r if rng.random() < 0.5 else r.translate(comp)[::-1])
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "wb") as fh:
+        fh.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads)))
+    m = 3
+    opt = Options.defaults(k, m, 2, False)
+    opt.max_distance_per_flank, opt.levenshtein_distance = maxd, lev
+    L = tj.lib()
+    h = tj.HopoCounter.new_or_append_from_file(None, fq, opt)
+    gl = L.new_genomic_context_list(h._p)
+    assert gl, "sample excluded"
+    g = gl.contents
+    # the oracle on the same reads
+    o = orc.Oracle(k)
+    o.scan_stream(np.frombuffer(b"".join(r + b"\n" for r in reads), np.uint8), m)
+    o.finalise(0, 2)
+    assert o.c.status == 0 and h.c.n_elem == o.c.n_elem and g.coverage == o.c.coverage
+    e = o.elems()
+    w = orc.genomic_context_list(e, k, maxd, lev, m)
+    wg = w["groups"]
+    assert g.n_hist == len(wg) and g.ref_start == 0 and g.name == os.fsencode(fq)
+    meta = orc.decode_meta(e["meta"])
+    n_indel = 0
+    for i in range(g.n_hist):
+        ch, x = g.hist[i].contents, wg[i]
+        f = int(x["first"])
+        assert (ch.n_context, ch.integral, ch.mode_context_count, ch.mode_context_length, ch.mode_context_id) == \
+            (x["n_context"], x["integral"], x["mode_context_count"], x["mode_context_length"], x["mode_context_id"]), i
+        assert (ch.indel != 0) == bool(x["indel"]) and ch.base == meta["base"][f] and ch.location == -1 and ch.tract_id == -1
+        n_indel += int(x["indel"])
+        assert [ch.context[t] for t in range(2 * ch.n_context)] == w["contexts"][f:f + ch.n_context].reshape(-1).tolist(), i
+        mo = int(x["mode"])
+        assert ch.name.decode() == orc.name_of(e["ctx0"][mo], e["ctx1"][mo], meta["base"][mo], k), i
+        hh = ch.h.contents
+        assert hh.n == x["n_len"] and [(hh.i[t].idx, hh.i[t].freq) for t in range(hh.n)] == \
+            list(zip(w["hist_len"][f:f + hh.n].tolist(), w["hist_freq"][f:f + hh.n].tolist())), i
+        assert hh.min == min(w["hist_len"][f:f + hh.n]) and hh.max == max(w["hist_len"][f:f + hh.n])
+    assert n_indel > 0 and g.n_hist < len(e)                 # the retry and the grouping both did something
+    L.del_genomic_context_list(gl)
+    h.delete()
 
 
 def test_tract_ids_and_in_process_gather():
