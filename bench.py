@@ -438,15 +438,18 @@ def main():
     # run inside the timed process), only when they were taken on this workload
     scan_kernel = "scan_fast_kernel<%d>" % (1 if k <= 12 else (2 if k <= 28 else 4))
     traffic, traffic_src = None, None
-    prof = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    try:
-        tj_prof = json.load(open(prof))
-        w = tj_prof.get("_workload", {})
-        if (w.get("reads"), w.get("read_len"), w.get("kmer"), w.get("min_tract")) == (args.reads, L, k, m) and args.read_len_max <= L:
-            traffic = {kk: vv for kk, vv in tj_prof.items() if isinstance(vv, dict) and "hbm_bytes" in vv}
-            traffic_src = "profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py), per launch"
-    except (OSError, ValueError, KeyError):
-        pass
+    import glob
+    for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):     # the latest round's passes first
+        try:
+            tj_prof = json.load(open(prof))
+            w = tj_prof.get("_workload", {})
+            if (w.get("reads"), w.get("read_len"), w.get("kmer"), w.get("min_tract")) == (args.reads, L, k, m) and args.read_len_max <= L:
+                traffic = {kk: vv for kk, vv in tj_prof.items() if isinstance(vv, dict) and "hbm_bytes" in vv}
+                traffic_src = ("profiles/" + os.path.basename(prof) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                               "(tools/pmc_traffic.py), per launch")
+                break
+        except (OSError, ValueError, KeyError):
+            pass
     roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_src}
     if dominant == "scan":
         roof.update({"kernel": scan_kernel, "achieved": scan_gbs, "frac": scan_gbs / HBM_PEAK_GBS, "ms": scan_avg, "algorithmic_bytes": scan_bytes})

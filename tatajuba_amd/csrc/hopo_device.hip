@@ -1362,7 +1362,7 @@ struct FastLds
   u32 code[FK_WIN / 16 + 4];            // 2-bit codes, 16 positions per word (+ zeroed pad for funnel reads)
   u32 st[FK_WIN / 32 + 4];              // run starts (byte differs from its predecessor)
   u32 lt[FK_WIN / 32 + 4];              // letters (not a read delimiter)
-  unsigned short cand[FK_MAXCAND + 2];
+  unsigned short cand[FK_MAXCAND + 2 + 64];         // (+ 64: a spare entry per lane, see FK_CAND_UNROLL)
   u32 ncand[4];                         // per tile, three in rotation (zeroed two tiles ahead)
   u32 bad[4];                           // per tile, likewise: some byte outside ACGT\n
   u32 grp[2];
@@ -1594,9 +1594,9 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         const u32 rec = __builtin_amdgcn_perm (NP ? 0x474E0054u : 0x47000054u, 0x430A4101u, sel);
         bad = __builtin_amdgcn_bitop3_b32 (bad, w, rec, BITOP3_OR_XOR);
         // 2-bit code (A 0, C 1, G 2, T 3; N 0; the delimiter 3, which no record ever packs) at bits 1-2 of every byte, gathered
-        // 4 bytes -> 8 bits (twice the value).  FK_CODE_LUT: by table look-up on the low three bits (one v_perm) instead of
-        // b ^ (b >> 1) masked (a shift and a v_bitop3): one instruction less per word
-#ifdef FK_CODE_LUT
+        // 4 bytes -> 8 bits (twice the value).  By table look-up on the low three bits (one v_perm; FK_CODE_XOR: as
+        // b ^ (b >> 1) masked, a shift and a v_bitop3 -- one instruction more per word, 241 -> 234.5 M vector instructions per launch)
+#ifndef FK_CODE_XOR
         const u32 cd = __builtin_amdgcn_perm (0x04000006u, 0x02060000u, sel);
 #else
         const u32 cd = __builtin_amdgcn_bitop3_b32 (w, M06, w >> 1, BITOP3_XOR_AND);
@@ -1656,6 +1656,19 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         u32 at = wbase + incl - n;
         // (tried: a loop on "any lane has one left" as a scalar branch, with the idle lanes writing to spare entries -- no
         // exec mask to keep per iteration, 11 M fewer scalar instructions per launch, and 4 % slower)
+#ifdef FK_CAND_UNROLL
+        // The first FK_CAND_UNROLL candidates of every lane without a loop (a lane has 1.5 on average, 98 in 100 have at most
+        // four): the loop's exec bookkeeping and branch are three scalar instructions per turn at the pace of the wave's
+        // busiest lane; here a lane without a candidate left writes to a spare entry of its own instead
+        const u32 spare_idx = (u32) FK_MAXCAND + 2u + (u32) lane;
+#pragma unroll
+        for (int j = 0; j < FK_CAND_UNROLL; j++) {
+          const u32 b = (u32) __ffs ((int) cand) - 1u;
+          T.cand[((u32) j < n) ? at + (u32) j : spare_idx] = (unsigned short) (p0 | b);
+          cand &= cand - 1u;
+        }
+        at += (u32) FK_CAND_UNROLL;
+#endif
         while (cand) {
           const u32 b = (u32) __ffs ((int) cand) - 1u;
           cand &= cand - 1u;

@@ -779,12 +779,14 @@ def test_full_size_properties_config3():
     """BASELINE config 3's parameters (150 bp reads, 50 Mb genome, k=15 m=4, strand-bias filter) on a 3 GB stream: the scan
     runs in the library's real 1 GiB pieces (three launches, cuts on read delimiters), two-word records, and the result
     has the properties that need no CPU pass at this size; a 1/16 sample agrees with the oracle exactly."""
-    n_reads, L, k, m = 20_000_000, 150, 15, 4
+    # (TATAJUBA_AMD_C3_READS=100000000 runs it at BASELINE's full size -- 15 GB, fourteen pieces, some 50 GB of host memory and
+    # a few minutes: done once per round by hand, DESIGN section 6 says with what outcome)
+    n_reads, L, k, m = int(os.environ.get("TATAJUBA_AMD_C3_READS", "20000000")), 150, 15, 4
     s = tj.synth_stream(n_reads, L, 50_000_000, n_threads=16)
     assert s.size > (3 << 30) // 2                              # more than 1.5 GiB: scanned piece by piece
     c = tj.Counter(k)
     c.scan_host(s, m)
-    assert c.last_scan_launches() >= 3
+    assert c.last_scan_launches() >= max(3, s.size >> 30)
     raw = c.raw_count()
     assert 1.25 < raw / n_reads < 1.5                           # r-bar ~ 1.37 (SURVEY 8a)
     assert c.finalise(1, 5) == 0
