@@ -1141,6 +1141,9 @@ struct StageSink
     }
     PSTAMP (12);
     if (wave < TJ_P / 64) {                             // where the reserved run lives: byte addresses of "sorted slot 0" for both parts
+      // (tried in round 3: the usual run -- inside the chunk its bucket was written to last time, opening no new one -- worked
+      // out without a branch and the rest behind one wave-wide test: 1.5 M vector and 0.5 M scalar instructions MORE per
+      // launch, 1 % slower; the exec regions below are cheaper than they look)
       u64 a1 = 0, a2 = 0;
       u32 thr = 0;
       if (cnt) {
@@ -1500,6 +1503,10 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   asm ("v_mov_b32 %0, 0x6D2B4F0B" : "=v"(vh0));
   asm ("v_mov_b32 %0, 0xC5A34D17" : "=v"(vh1));
   asm ("v_mov_b32 %0, 0x07FFFFFF" : "=v"(vm27));
+  u32 v_st_base, v_lt_base, v_cd_base;                    // LDS addresses of the three planes (phase 3's window reads)
+  asm ("v_mov_b32 %0, %1" : "=v"(v_st_base) : "s"((u32) (size_t) (lptr_t) &T.st[0]));
+  asm ("v_mov_b32 %0, %1" : "=v"(v_lt_base) : "s"((u32) (size_t) (lptr_t) &T.lt[0]));
+  asm ("v_mov_b32 %0, %1" : "=v"(v_cd_base) : "s"((u32) (size_t) (lptr_t) &T.code[0]));
   u32 own = (tid == 0 || tid >= (FK_WIN - FK_HR) / FK_UNIT) ? 0u : 0xFFFFFFFFu;   // halo lanes own no tract start
   asm volatile ("" : "+v"(own));                        // (a VGPR, not a condition that is looked up in spilled SGPRs per tile)
   const u32 voff16 = 16u * (u32) lane;
@@ -1538,20 +1545,22 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   // first byte.  The stream's first and last tiles are done here too: their chunks that stick out are fetched from a
   // valid address instead and phase 1 overwrites what lies outside the stream with read delimiters (edge_chunk).
   u32 pred = 0;
+  // (the interior test comes first and stands for "there is such a tile" as well: tiles 1 .. t_hi all exist, so the usual
+  // tile pays one compare, not two; its byte offset is non-negative and is added as an unsigned number)
   auto prefetch = [&] (int t) {
     const int g0w = t * FK_OWN - FK_HL + 2048 * wave;   // stream position of the wave's first byte
     if ((u32) (t - 1) < (u32) t_hi) {
-      const uint8_t *g = seq + g0w;
+      const uint8_t *g = seq + (u32) g0w;
       lds_dma32 (g, voff16, &raw[128 * wave]);
       pred = *reinterpret_cast<const u32 *> (g - 4);
     }
-    else {
+    else if (t < nt_all) {
       issue_chunk (seq, n_bytes, (long) g0w + 16l * lane, &raw[128 * wave]);
       issue_chunk (seq, n_bytes, (long) g0w + 1024l + 16l * lane, &raw[128 * wave + 64]);
       pred = stream_byte (seq, n_bytes, (long) g0w - 1) << 24;
     }
   };
-  if (tile < nt_all) prefetch (tile);
+  prefetch (tile);
   u32 n_sbuf = 0;                                       // (workgroup-uniform)
   auto flush_slow = [&] () {
     if (wave == 0 && n_sbuf) {                          // (thread 0 wrote the entries: same wave, LDS keeps its order)
@@ -1593,14 +1602,10 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         // hold bytes with other low bits: they can never match; the second chance has 'N' at 6)
         const u32 rec = __builtin_amdgcn_perm (NP ? 0x474E0054u : 0x47000054u, 0x430A4101u, sel);
         bad = __builtin_amdgcn_bitop3_b32 (bad, w, rec, BITOP3_OR_XOR);
-        // 2-bit code (A 0, C 1, G 2, T 3; N 0; the delimiter 3, which no record ever packs) at bits 1-2 of every byte, gathered
-        // 4 bytes -> 8 bits (twice the value).  By table look-up on the low three bits (one v_perm; FK_CODE_XOR: as
-        // b ^ (b >> 1) masked, a shift and a v_bitop3 -- one instruction more per word, 241 -> 234.5 M vector instructions per launch)
-#ifndef FK_CODE_XOR
-        const u32 cd = __builtin_amdgcn_perm (0x04000006u, 0x02060000u, sel);
-#else
-        const u32 cd = __builtin_amdgcn_bitop3_b32 (w, M06, w >> 1, BITOP3_XOR_AND);
-#endif
+        // 2-bit code (A 0, C 1, G 2, T 3; N 0; the delimiter 3, which no record ever packs) by table look-up on the low three
+        // bits (one v_perm; round 2 took bits 1-2 of b ^ (b >> 1): a shift and a v_bitop3, and codes that sat one bit up),
+        // gathered 4 bytes -> 8 bits
+        const u32 cd = __builtin_amdgcn_perm (0x02000003u, 0x01030000u, sel);
         r[j] = __builtin_amdgcn_udot4 (cd, 0x40100401u, 0u, false);
         // letters have bit 6 ('\n' has not): 64 x the byte of 8 flags per pair of words
         const u32 wts = (j & 1) ? 0x80402010u : 0x08040201u;
@@ -1612,10 +1617,18 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         if constexpr (NP) nc[j >> 1] = __builtin_amdgcn_udot4 (__builtin_amdgcn_perm (0x00010000u, 0u, sel), wts, nc[j >> 1], false);
         selp = sel;
       }
-      const u32 code_lo = (r[0] >> 1) | (r[1] << 7) | (r[2] << 15) | (r[3] << 23);
-      const u32 code_hi = (r[4] >> 1) | (r[5] << 7) | (r[6] << 15) | (r[7] << 23);
-      S32 = sc[0] | (sc[1] << 8) | (sc[2] << 16) | (sc[3] << 24);
-      L32 = ((lc[0] | (lc[1] << 8)) >> 6) | (((lc[2] | (lc[3] << 8)) >> 6) << 16);
+      // four gathered bytes -> one word with two byte permutes and an OR (as shifts and ORs the compiler spent seven
+      // instructions per word here, 26 per tile and lane for the three planes; now 13)
+      auto pack4 = [] (u32 b0, u32 b1, u32 b2, u32 b3) {
+        return __builtin_amdgcn_perm (b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm (b3, b2, 0x04000c0cu);
+      };
+      const u32 code_lo = pack4 (r[0], r[1], r[2], r[3]);
+      const u32 code_hi = pack4 (r[4], r[5], r[6], r[7]);
+      S32 = pack4 (sc[0], sc[1], sc[2], sc[3]);
+      {                                                   // (the letter flags come 64-fold: bit 6 of the bytes)
+        const u32 u = lc[0] | (lc[1] << 8), v = lc[2] | (lc[3] << 8);
+        L32 = (u >> 6) | (v << 10);
+      }
       *reinterpret_cast<uint2 *> (&T.code[2 * tid]) = make_uint2 (code_lo, code_hi);
       T.st[tid] = S32;
       T.lt[tid] = L32;
@@ -1700,7 +1713,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     int nt = tile + 1;
     if (nt >= grp_end) nt = __builtin_amdgcn_readfirstlane ((int) T.grp[gpar ^ 1u]);
     asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw has been read: it may be refilled
-    if (nt < nt_all) prefetch (nt);
+    prefetch (nt);
     STAMP (3);
 
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 1          // experiment builds only (tools/exp_fast_phases.sh)
@@ -1781,7 +1794,14 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         const bool valid = ci < ncand;
         const u32 s = T.cand[min (ci, ncand - 1)];
         const u32 q = s + 1u, u = s - vk;
-        const u32 *ps = &T.st[q >> 5], *pl = &T.lt[u >> 5], *pc = &T.code[u >> 4];
+        // (word addresses as shift + v_lshl_add_u32 on the planes' LDS addresses: left to itself the compiler turns
+        // base + 4 * (x >> 5) into shift, mask and add, three instructions per plane instead of two)
+        typedef __attribute__((address_space(3))) const u32 *lds_words_t;
+        u32 a_st, a_lt, a_cd;
+        asm ("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a_st) : "v"(q >> 5), "v"(v_st_base));
+        asm ("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a_lt) : "v"(u >> 5), "v"(v_lt_base));
+        asm ("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a_cd) : "v"(u >> 4), "v"(v_cd_base));
+        const lds_words_t ps = (lds_words_t) (size_t) a_st, pl = (lds_words_t) (size_t) a_lt, pc = (lds_words_t) (size_t) a_cd;
         u32 s0 = ps[0], s1 = ps[1], l0 = pl[0], l1 = pl[1], w0 = pc[0], w1 = pc[1], w2 = pc[2];
         // (pinned: left alone the compiler waits for the run starts before it asks for the codes, and reads the letters
         // only inside a branch it makes up -- three LDS round trips in a row instead of one)
@@ -1828,9 +1848,10 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         const bool rev = cb >= 2u;
         const u32 c0 = rev ? rcr : l, c1 = rev ? rcl : r;
         // base << 2 | flag << 3 by table look-up on cb: A (0, fwd) 8, C (1, fwd) 12, G (-> C, rev) 20, T (-> A, rev) 16
-        const u32 fld = __builtin_amdgcn_perm (0u, 0x10140C08u, cb | 0x0C0C0C00u);
+        // (looked up straight into the record's top byte: selector byte 3 = cb, the others "zero")
+        const u32 fld24 = __builtin_amdgcn_perm (0u, 0x10140C08u, (cb << 24) | 0x000C0C0Cu);
         const u32 lo = c1 | (len << 24);
-        const u32 hi = c0 | (fld << 24);
+        const u32 hi = c0 | fld24;
         STAMP (6);
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
         if (ok) asm volatile ("" :: "v"(lo), "v"(hi), "v"(at));
