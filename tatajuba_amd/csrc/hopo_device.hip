@@ -1162,6 +1162,11 @@ struct StageSink
       L.split[tid] = thr; L.gbase[tid] = a1; L.gbase2[tid] = a2;
     }
     PSTAMP (13);
+    // Everything this wave has asked global memory for so far (the cursor's atomic, chunk ids, the tile's prefetch) is waited
+    // for HERE, with the compiler's own instruction, before the first store below: from now on nothing is in flight that
+    // anybody waits for but stores -- otherwise the compiler, unsure on which path a chunk id was fetched, puts a vmcnt(0)
+    // where the tile loop's paths meet, in the classification of every tile, and that one waits for the stores too.
+    __builtin_amdgcn_s_waitcnt (0x0F70);                // vmcnt(0) alone
     lds_barrier ();
     PSTAMP (14);
 #pragma unroll
@@ -1184,12 +1189,16 @@ struct StageSink
           const u32 i = (u32) tid + (u32) (r0 + h) * BLOCK;
           const u64 a = (i < cthr[h]) ? ca1[h] : ca2[h];
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 3
-          if (a == 0x123456789ull)
+          const bool st = a == 0x123456789ull;
 #else
-          if ((FULL || i < n) && a != 0ull)
+          const bool st = (FULL || i < n) && a != 0ull;
 #endif
-          {
-            u64 *q = reinterpret_cast<u64 *> (a + (8ull * W) * i);
+          if (st) {
+            // (a pointer into the global address space, said so: made from an integer it is a generic pointer to the compiler, the
+            // stores become flat_store -- which counts in lgkmcnt as well, completes out of order, and makes every later
+            // wait of the wave a full drain of both counters)
+            typedef __attribute__((address_space(1))) u64 *gwords_t;
+            gwords_t q = (gwords_t) (a + (8ull * W) * i);
 #pragma unroll
             for (int j = 0; j < WS; j++) q[j] = cw[h][j];
             if (WS < W) q[W - 1] = 0;
@@ -1503,10 +1512,6 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   asm ("v_mov_b32 %0, 0x6D2B4F0B" : "=v"(vh0));
   asm ("v_mov_b32 %0, 0xC5A34D17" : "=v"(vh1));
   asm ("v_mov_b32 %0, 0x07FFFFFF" : "=v"(vm27));
-  u32 v_st_base, v_lt_base, v_cd_base;                    // LDS addresses of the three planes (phase 3's window reads)
-  asm ("v_mov_b32 %0, %1" : "=v"(v_st_base) : "s"((u32) (size_t) (lptr_t) &T.st[0]));
-  asm ("v_mov_b32 %0, %1" : "=v"(v_lt_base) : "s"((u32) (size_t) (lptr_t) &T.lt[0]));
-  asm ("v_mov_b32 %0, %1" : "=v"(v_cd_base) : "s"((u32) (size_t) (lptr_t) &T.code[0]));
   u32 own = (tid == 0 || tid >= (FK_WIN - FK_HR) / FK_UNIT) ? 0u : 0xFFFFFFFFu;   // halo lanes own no tract start
   asm volatile ("" : "+v"(own));                        // (a VGPR, not a condition that is looked up in spilled SGPRs per tile)
   const u32 voff16 = 16u * (u32) lane;
@@ -1691,7 +1696,11 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       }
     };
     {
-      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has landed in raw
+      // This wave's part of the tile has landed in raw.  (Tried in round 3: a counted wait -- vmcnt(7) when a full partition
+      // pass, whose last seven vector-memory operations are its stores, has run since the prefetch -- so that the stores
+      // need not be waited for.  It needs the predecessor word loaded outside the compiler's view, into a register that
+      // the compiler then copies before the word has arrived; through LDS it would cost what it gains, 1.7 %.)
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP (1);
       const uint4 va = raw[2 * tid], vb = raw[2 * tid + 1];
       x[0] = va.x; x[1] = va.y; x[2] = va.z; x[3] = va.w; x[4] = vb.x; x[5] = vb.y; x[6] = vb.z; x[7] = vb.w;
@@ -1702,6 +1711,9 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
           const long g = p0 + 16l * h;
           if (!(g >= 0 && g + 16 <= n_bytes)) {
             const EdgeChunk e = edge_chunk (seq, n_bytes, g);      // (outside the stream everything is a read delimiter)
+            // (the wait for whatever the call left in flight, here: left to the compiler it sits where the two paths meet,
+            // in the classification of EVERY tile, as vmcnt(0) -- which would also wait for the stores of a partition pass)
+            __builtin_amdgcn_s_waitcnt (0x0F70);          // vmcnt(0) only
             x[4 * h] = e.x; x[4 * h + 1] = e.y; x[4 * h + 2] = e.z; x[4 * h + 3] = e.w;
           }
         }
@@ -1794,14 +1806,10 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         const bool valid = ci < ncand;
         const u32 s = T.cand[min (ci, ncand - 1)];
         const u32 q = s + 1u, u = s - vk;
-        // (word addresses as shift + v_lshl_add_u32 on the planes' LDS addresses: left to itself the compiler turns
-        // base + 4 * (x >> 5) into shift, mask and add, three instructions per plane instead of two)
-        typedef __attribute__((address_space(3))) const u32 *lds_words_t;
-        u32 a_st, a_lt, a_cd;
-        asm ("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a_st) : "v"(q >> 5), "v"(v_st_base));
-        asm ("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a_lt) : "v"(u >> 5), "v"(v_lt_base));
-        asm ("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a_cd) : "v"(u >> 4), "v"(v_cd_base));
-        const lds_words_t ps = (lds_words_t) (size_t) a_st, pl = (lds_words_t) (size_t) a_lt, pc = (lds_words_t) (size_t) a_cd;
+        // (tried: the word addresses as shift + v_lshl_add_u32 on the planes' LDS addresses, two instructions per plane
+        // instead of the compiler's three -- the three base addresses in VGPRs were three registers too many at this
+        // kernel's 128-register edge once the counted wait below needed one)
+        const u32 *ps = &T.st[q >> 5], *pl = &T.lt[u >> 5], *pc = &T.code[u >> 4];
         u32 s0 = ps[0], s1 = ps[1], l0 = pl[0], l1 = pl[1], w0 = pc[0], w1 = pc[1], w2 = pc[2];
         // (pinned: left alone the compiler waits for the run starts before it asks for the codes, and reads the letters
         // only inside a branch it makes up -- three LDS round trips in a row instead of one)
