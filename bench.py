@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=None,
                     help="a BASELINE.json configuration (SURVEY 8d numbering; 2 = configs[1] = the headline = the default sizes)")
+    ap.add_argument("--order-stream", action="store_true", help="the ordering step of a sample's finalise on a stream of its own (tjamd_counter_set_order_stream) instead of the scan's; measured: 0.832 against 0.824 ms per step, so not the default")
     ap.add_argument("--no-io-stages", action="store_true", help="skip the host-memory and FASTQ-file throughputs (stages.from_host / from_file)")
     ap.add_argument("--io-reads", type=int, default=2_000_000, help="reads of the sample used for stages.from_host / from_file")
     ap.add_argument("--gz-reads", type=int, default=500_000, help="reads of the sample used for stages.from_gzip / from_bgzf")
@@ -289,8 +290,15 @@ def main():
     # is already queued -- a step is still one whole sample, scanned and finalised, and K samples begin and end inside the
     # timed region.
     ctrs = [tj.Counter(k, device=local) for _ in range(2)]
+    # (--order-stream) a second stream for the ordering step of a sample's finalise (six small launches, latency-shaped): it
+    # runs behind an event, under the next sample's scan, which the first stream has queued on the other counter.  Measured
+    # in round 3: no gain (the scan fills every CU, the small kernels wait for its workgroups to retire and delay it by as
+    # much as they save), so the default stays one stream.
+    order = torch.cuda.Stream() if args.order_stream else None
     for cc in ctrs:
         cc.set_stream(stream.cuda_stream)
+        if order is not None:
+            cc.set_order_stream(order.cuda_stream)
     c = ctrs[0]
     side = merger = None
     if world > 1:
@@ -470,7 +478,8 @@ def main():
                                + (f", read length uniform in [{L}, {args.read_len_max}]" if args.read_len_max > L else "") + " -- " + workload_label(args),
                    "reads_per_gpu": args.reads, "raw_records_per_gpu": int(raw), "kept_records": int(kept),
                    "parallelism": f"sample-per-gpu x{world}" + (", histogram exchange (all-gatherv + merge) overlapped with the next sample's scan" if world > 1 else ""),
-                   "pipelining": "two counters take turns on one stream: sample i's counts are fetched (tjamd_finalise_end) after sample i + 1 has been queued; every step is a whole sample, K begin and end inside the timed region"},
+                   "pipelining": "two counters take turns on one stream: sample i's counts are fetched (tjamd_finalise_end) after sample i + 1 has been queued; every step is a whole sample, K begin and end inside the timed region"
+                                 + ("" if not args.order_stream else "; the ordering step of sample i's finalise (six small launches) runs on a second stream, under sample i + 1's scan")},
         "roofline": roof,
         "stages": {"scan": {"ms": scan_avg, "algorithmic_GBps": scan_gbs, "frac_of_hbm_peak": scan_gbs / HBM_PEAK_GBS,
                             "reads_per_s": args.reads / (scan_avg * 1e-3), "kernel": scan_kernel,

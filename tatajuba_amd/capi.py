@@ -85,7 +85,7 @@ EXPORTS = [
     "leftmost_hopo_name_and_length_from_string", "hopo_counter_histogram_integral",
     "dna_in_2_bits", "bit_2_dna",
     "tjamd_device_count", "tjamd_source_hash", "tjamd_last_error", "tjamd_version", "tjamd_counter_create", "tjamd_counter_destroy",
-    "tjamd_counter_reset", "tjamd_counter_set_stream", "tjamd_counter_device", "tjamd_scan_device", "tjamd_scan_host",
+    "tjamd_counter_reset", "tjamd_counter_set_stream", "tjamd_counter_set_order_stream", "tjamd_counter_device", "tjamd_scan_device", "tjamd_scan_host",
     "tjamd_scan_host_located", "tjamd_read_file_stream_mt", "tjamd_host_alloc", "tjamd_host_free", "tjamd_device_alloc", "tjamd_device_free", "tjamd_device_download", "tjamd_sync", "tjamd_mark", "tjamd_wait_mark", "tjamd_reserve", "tjamd_raw_count",
     "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_finalise_begin", "tjamd_finalise_end", "tjamd_kept_count",
     "tjamd_n_idx", "tjamd_coverage", "tjamd_download_kept", "tjamd_download_idx", "tjamd_kept_device_ptr",
@@ -372,6 +372,11 @@ class Counter:
 
     def set_stream(self, hip_stream):
         self._chk(lib().tjamd_counter_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_order_stream(self, hip_stream):
+        """second stream for the ordering step of finalise_begin / finalise_end (tjamd_counter_set_order_stream); None: none"""
+        lib().tjamd_counter_set_order_stream.argtypes = [C.c_void_p, C.c_void_p]
+        self._chk(lib().tjamd_counter_set_order_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
     def sync(self):
         self._chk(lib().tjamd_sync(self._h))

@@ -1067,6 +1067,7 @@ struct StageSink
       // room for fits, n + BLOCK <= S, and the exact count is what it gets back; only finish () empties a partial buffer,
       // so that the loop holds one copy of the pass, the one without tests)
       if (n >= (u32) PS || final_pass) return final_pass ? partition_pass<false> (n) : partition_pass<true> (n);
+      lds_barrier ();                                   // (rare path; nobody appends before everybody has read n)
       return n;
     }
     else return partition_pass<false> (n);
@@ -1734,6 +1735,11 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #endif
     find_candidates (ncand_addr + 4u * slot, false);
     STAMP (4);
+    // the records staged so far, exactly: read BEFORE the barrier -- between the barrier that ended the tile before and
+    // this one nobody appends, so every wave reads the same number; behind the barrier the quick waves are already
+    // appending this tile's records while a slow one has yet to look (seen: one scan in fifty lost some eighty records
+    // when a wave got a larger number, partitioned on its own schedule and its barriers paired up with the others' wrongly)
+    const u32 staged_v = SL.n;
 #if !(defined(FK_EXP_NOBAR) && (FK_EXP_NOBAR & 2))
     lds_barrier ();
 #endif
@@ -1745,9 +1751,9 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #else
     const u32 ncand_all = (u32) __builtin_amdgcn_readfirstlane ((int) T.ncand[slot]);
 #endif
-    // the records staged so far, exactly (every append of the tiles before is behind a barrier): `bound` has counted
-    // candidates, of which one in eight is not recorded -- with the true count the buffer is partitioned when it is full
-    sink.bound = (u32) __builtin_amdgcn_readfirstlane ((int) SL.n);
+    // (`bound` has counted candidates, of which one in eight is not recorded -- with the true count the buffer is
+    // partitioned when it is full)
+    sink.bound = (u32) __builtin_amdgcn_readfirstlane ((int) staged_v);
     u32 ncand_now = ncand_all;
     if (ncand_all >= 0x40000000u) {
       // Second chance for a tile with a byte outside the five: if all such bytes are 'N' (the no-call of every sequencer),
@@ -3435,6 +3441,8 @@ struct tjamd_counter
   long n_kept = 0; int n_idx = 0, coverage = 0, status = -1;
   hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_f0 = nullptr, ev_f1 = nullptr;
   hipEvent_t ev_done = nullptr;                         // tjamd_finalise_begin: the counts have reached the host
+  hipEvent_t ev_agg = nullptr;                          // the aggregation and the clearing of the buckets are done (order_stream waits for it)
+  hipStream_t order_stream = nullptr;                   // tjamd_counter_set_order_stream: where a finalise begun with tjamd_finalise_begin runs its ordering step
   int fin_pending = 0;                                  // 1: begun, results not looked at yet (tjamd_finalise_end)
   int fin_rb = 0, fin_mc = 0; bool fin_speculative = false, fin_plan_ahead = false; u64 fin_kept_cap = 0;
   hipEvent_t marks[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // tjamd_mark / tjamd_wait_mark
@@ -3501,6 +3509,7 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   HIPCHK_NULL (hipEventCreate (&c->ev_s0)); HIPCHK_NULL (hipEventCreate (&c->ev_s1));
   HIPCHK_NULL (hipEventCreate (&c->ev_f0)); HIPCHK_NULL (hipEventCreate (&c->ev_f1));
   HIPCHK_NULL (hipEventCreateWithFlags (&c->ev_done, hipEventDisableTiming));
+  HIPCHK_NULL (hipEventCreateWithFlags (&c->ev_agg, hipEventDisableTiming));
   HIPCHK_NULL (hipStreamSynchronize (c->stream));
   return c;
 }
@@ -3522,6 +3531,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   if (c->ev_f0) (void) hipEventDestroy (c->ev_f0);
   if (c->ev_f1) (void) hipEventDestroy (c->ev_f1);
   if (c->ev_done) (void) hipEventDestroy (c->ev_done);
+  if (c->ev_agg) (void) hipEventDestroy (c->ev_agg);
   if (c->own_stream) (void) hipStreamDestroy (c->own_stream);
   delete c;
 }
@@ -3534,6 +3544,20 @@ extern "C" int tjamd_counter_set_stream (tjamd_counter *c, void *hip_stream)
   HIPCHK (hipSetDevice (c->device));
   HIPCHK (hipStreamSynchronize (c->stream));
   c->stream = hip_stream ? (hipStream_t) hip_stream : c->own_stream;
+  return TJAMD_OK;
+}
+
+// A second stream for the ordering step of a finalise that was begun with tjamd_finalise_begin (null: none).  The step is
+// six small launches whose time is latency, not work (110 us for 234 k records): behind an event on the counter's stream
+// it runs beside whatever that stream does next -- the scan of the next sample on another counter -- and
+// tjamd_finalise_end waits for its last copy as before.  The counter itself must not be touched between the two calls.
+extern "C" int tjamd_counter_set_order_stream (tjamd_counter *c, void *hip_stream)
+{
+  if (!c) return set_err (TJAMD_ERR_ARG, "null counter");
+  HIPCHK (hipSetDevice (c->device));
+  HIPCHK (hipStreamSynchronize (c->stream));
+  if (c->order_stream) HIPCHK (hipStreamSynchronize (c->order_stream));
+  c->order_stream = (hipStream_t) hip_stream;
   return TJAMD_OK;
 }
 
@@ -4111,6 +4135,9 @@ static int finalise_radix (tjamd_counter *c, long n1, int min_coverage)
 static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long cap = 0, bool wait = true)
 {
   const bool planned = n1 == 0;
+  // (begun, not waited for, and a second stream is there: the step goes to it, behind what the counter's stream holds so far)
+  const bool aside = planned && !wait && c->order_stream != nullptr && c->order_stream != c->stream;
+  const hipStream_t st = aside ? c->order_stream : c->stream;
   const FinPlan *plan = planned ? &c->d_state->plan : nullptr;
   if (planned) n1 = cap;                                // (sizes everything below; the kernels use the plan's numbers)
   const int nbits = bin_bits_for (n1, c->k);
@@ -4132,25 +4159,26 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long ca
   u64 *ctab = (u64 *) c->cov.p;
   if (!c->bins_zeroed) HIPCHK (hipMemsetAsync (bins, 0, (size_t) BS_MAXBINS * 4, c->stream));
   c->bins_zeroed = false;
+  if (aside) { HIPCHK (hipEventRecord (c->ev_agg, c->stream)); HIPCHK (hipStreamWaitEvent (st, c->ev_agg, 0)); }
   // (planned: the grids are sized for a typical kept count, not for the buffers' capacity -- the kernels stride)
   const unsigned g1 = planned ? std::min<unsigned> (grid_for (n1), 2048u) : grid_for (n1);
-  hipLaunchKernelGGL (bin_count_kernel, dim3 (g1), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, n1, c->k, nbits, bins,
+  hipLaunchKernelGGL (bin_count_kernel, dim3 (g1), dim3 (256), 0, st, (const u64 *) c->kept.p, n1, c->k, nbits, bins,
                       (uint4 *) c->cov.p, (long) (t / 2), 0, plan);
-  hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, bins, nbins, binstart, c->bin_rank_max, c->d_fin, plan);
-  hipLaunchKernelGGL (bin_scatter_kernel, dim3 (g1), dim3 (256), 0, c->stream, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins, plan);
-  hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 16384)), dim3 (64 * BSI_WAVES), 0, c->stream,
+  hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, st, bins, nbins, binstart, c->bin_rank_max, c->d_fin, plan);
+  hipLaunchKernelGGL (bin_scatter_kernel, dim3 (g1), dim3 (256), 0, st, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins, plan);
+  hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 16384)), dim3 (64 * BSI_WAVES), 0, st,
                       (const u64 *) c->alt.p, (u64 *) c->kept.p, (const u32 *) binstart, nbins, (const FinCounts *) c->d_fin, min_coverage,
                       ctab, log2t, binctx, tstart, tend, plan);
-  hipLaunchKernelGGL (bin_ctx_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, (const u32 *) binctx, nbins, binout, c->d_fin, plan);
-  hipLaunchKernelGGL (bin_ctx_write_kernel, dim3 (256), dim3 (256), 0, c->stream, (const u32 *) binstart, (const u32 *) binctx, (const u32 *) binout, nbins,
+  hipLaunchKernelGGL (bin_ctx_scan_kernel, dim3 (1), dim3 (1024), 0, st, (const u32 *) binctx, nbins, binout, c->d_fin, plan);
+  hipLaunchKernelGGL (bin_ctx_write_kernel, dim3 (256), dim3 (256), 0, st, (const u32 *) binstart, (const u32 *) binctx, (const u32 *) binout, nbins,
                       (const u32 *) tstart, (const u32 *) tend, (int *) c->idx_i.p, (int *) c->idx_f.p, (const u64 *) ctab, t, c->d_fin, plan);
   HIPCHK (hipGetLastError ());
-  HIPCHK (hipEventRecord (c->ev_f1, c->stream));
+  HIPCHK (hipEventRecord (c->ev_f1, st));
   c->fin_timed = true;
-  if (planned) HIPCHK (hipMemcpyAsync (c->h_state, c->d_state, sizeof (DevState), hipMemcpyDeviceToHost, c->stream));   // (counts of the sample, plan, results: one copy)
+  if (planned) HIPCHK (hipMemcpyAsync (c->h_state, c->d_state, sizeof (DevState), hipMemcpyDeviceToHost, st));   // (counts of the sample, plan, results: one copy)
   else HIPCHK (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream));
   if (wait) HIPCHK (hipStreamSynchronize (c->stream));
-  else HIPCHK (hipEventRecord (c->ev_done, c->stream));
+  else HIPCHK (hipEventRecord (c->ev_done, st));
   return TJAMD_OK;
 }
 

@@ -63,6 +63,11 @@ while time.time() < t_end:
     try:
         assert c.raw_count() == o.c.n_elem, "raw count"
         if rng.random() < 0.4:                            # the same in two calls (tjamd_finalise_begin / _end)
+            if rng.random() < 0.5:                        # ... with the ordering step on a second stream
+                import torch
+                if "_order" not in globals():
+                    globals()["_order"] = torch.cuda.Stream()
+                c.set_order_stream(_order.cuda_stream)
             c.finalise_begin(rb, mc); st = c.finalise_end()
         else:
             st = c.finalise(rb, mc)
