@@ -120,7 +120,7 @@ struct FinCounts { u32 n_seg, n_kept, n_ctx, n_idx; int coverage; u32 overflow, 
 // The sizes the ordering kernels work with, derived on the device from the number of kept records so that the host does
 // not have to fetch that number between the aggregation and them (plan_tail; ok = 0: nothing to do, or more records
 // than the buffers were sized for -- every kernel then returns at once and the host takes the exact path).
-struct FinPlan { long n1; long t; int nbits, nbins, log2t, ok; u32 kept_overflow, pad; long n1_exact; u32 ovf_exact, pad2; };   // (n1_exact, ovf_exact: read at the kernel boundary after the aggregation, see clear_buckets_kernel)
+struct FinPlan { long n1; long t; int nbits, nbins, log2t, ok; u32 kept_overflow, cov_direct; long n1_exact; u32 ovf_exact, pad2; };   // (n1_exact, ovf_exact: read at the kernel boundary after the aggregation, see clear_buckets_kernel)
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -946,8 +946,8 @@ struct StageLds
   static constexpr int S = WORDS / WS;                   // records
   static constexpr int SPARE = BIG ? 64 : 0;
   u64 rec[WORDS + SPARE * WS];                          // (BIG: slots S + lane take the writes of lanes without a record)
-  u64 gbase[TJ_P];                                      // pool index of the first record of the bucket's run (BIG: byte address of sorted slot 0's place, see partition_big)
-  u64 gbase2[TJ_P];                                     // pool index of the part of the run that lies in the next chunk (BIG: likewise)
+  alignas (16) u64 gbase[TJ_P];                         // pool index of the first record of the bucket's run (BIG: gbase + gbase2 = 256 entries of 16 bytes, see partition_pass)
+  u64 gbase2[TJ_P];                                     // pool index of the part of the run that lies in the next chunk
   alignas (16) u32 hist[TJ_P + SPARE];                  // (BIG: entries TJ_P + lane are for the lanes without a record)
   alignas (16) u32 offs[TJ_P + SPARE];                               // start of the bucket's run in the sorted staging buffer
   u32 split[TJ_P];                                      // records of the run before the chunk boundary (BIG: first sorted slot past it)
@@ -955,6 +955,9 @@ struct StageLds
   u32 n;
   unsigned char bin[S + SPARE];
 };
+
+typedef StageLds<1, true> StageLdsFast1;
+static_assert (offsetof (StageLdsFast1, gbase2) == offsetof (StageLdsFast1, gbase) + sizeof (u64) * TJ_P, "gbase and gbase2 back to back");
 
 template <int W, int BLOCK, bool BIG = false>
 struct StageSink
@@ -1160,7 +1163,9 @@ struct StageSink
           if (cur_chunk != TJ_NOCHUNK) a2 = (u64) (size_t) (B.pool + ((u64) cur_chunk * ch) * W) - (8ull * W) * thr;
         }
       }
-      L.split[tid] = thr; L.gbase[tid] = a1; L.gbase2[tid] = a2;
+      // one 16-byte entry per bucket, read with one LDS instruction per record in the copy-out: [a1 low | a1 high (16 bits:
+      // device addresses have 48) + thr << 16 | a2]   (gbase and gbase2 lie back to back: 256 x 16 bytes)
+      reinterpret_cast<uint4 *> (L.gbase)[tid] = make_uint4 ((u32) a1, (u32) (a1 >> 32) | (thr << 16), (u32) a2, (u32) (a2 >> 32));
     }
     PSTAMP (13);
     // Everything this wave has asked global memory for so far (the cursor's atomic, chunk ids, the tile's prefetch) is waited
@@ -1181,7 +1186,8 @@ struct StageSink
         for (int h = 0; h < H; h++) if (r0 + h < RR) {
           const u32 i = (u32) tid + (u32) (r0 + h) * BLOCK;
           const u32 b = cb[h] & (u32) (TJ_P - 1);       // (slots past n hold stale bytes: any bucket will do, the store is masked)
-          cthr[h] = L.split[b]; ca1[h] = L.gbase[b]; ca2[h] = L.gbase2[b];
+          const uint4 e = reinterpret_cast<const uint4 *> (L.gbase)[b];
+          cthr[h] = e.y >> 16; ca1[h] = ((u64) (e.y & 0xFFFFu) << 32) | e.x; ca2[h] = ((u64) e.w << 32) | e.z;
 #pragma unroll
           for (int j = 0; j < WS; j++) cw[h][j] = L.rec[i * WS + j];
         }
@@ -1943,7 +1949,7 @@ __global__ void init_table_kernel (u32 *table, u32 maxj, u32 *pool_next)
 // One workgroup per bucket; only the row entries the bucket can have claimed are rewritten (its records / chunk + the
 // one claimed ahead), unless the whole row is asked for.
 __global__ void clear_buckets_kernel (u32 *cursors, DevCounters *ctr, u32 *table, u32 maxj, int ch_shift, FinCounts *fin, u32 *bins, int nbins,
-                                      DevCounters *snap_ctr, u32 *snap_cursors, FinPlan *plan)
+                                      DevCounters *snap_ctr, u32 *snap_cursors, FinPlan *plan, u32 *__restrict__ fine = nullptr, int fine_bits = 0)
 {
   const u32 b = blockIdx.x;
   if (snap_ctr) {                                       // (every workgroup reads its own cursor, workgroup 0 the rest: before anything is zeroed)
@@ -1968,7 +1974,32 @@ __global__ void clear_buckets_kernel (u32 *cursors, DevCounters *ctr, u32 *table
     if (ch_shift >= 0) used = min (maxj, ((cursors[b] / TJ_CH0) >> ch_shift) + 3u);
     for (u32 j = threadIdx.x; j < used; j += blockDim.x) table[(u64) b * maxj + j] = j ? TJ_EMPTY : b;
   }
-  if (bins) for (int i = (int) (b * blockDim.x + threadIdx.x); i < nbins; i += (int) (gridDim.x * blockDim.x)) bins[i] = 0;
+  if (fine) {
+    // The aggregation before this kernel has counted the records it kept into 2^fine_bits bins (the finest partition the
+    // ordering step can ask for); its plan says how many leading bits the step uses: a bin of the step is a run of
+    // 2^shift fine ones (a bin is a prefix of the key).  Summed here, one run per thread, which also zeroes what it has
+    // read for the next aggregation (loads first: a store to the array between two loads of it serialises them) -- this
+    // replaces the step's counting pass over the kept records.  No usable plan: the counts go, the step counts again.
+    const int gid = (int) (b * blockDim.x + threadIdx.x), gsz = (int) (gridDim.x * blockDim.x);
+    if (plan->ok) {
+      const int shift = fine_bits - plan->nbits, run = 1 << shift, nb = plan->nbins;
+      for (int i = gid; i < nb; i += gsz) {
+        u32 sum = 0;
+        if (shift >= 2) {
+          uint4 *f4 = reinterpret_cast<uint4 *> (fine) + (size_t) i * (run >> 2);
+          for (int j = 0; j < (run >> 2); j++) { const uint4 v = f4[j]; sum += v.x + v.y + v.z + v.w; }
+          for (int j = 0; j < (run >> 2); j++) f4[j] = make_uint4 (0, 0, 0, 0);
+        }
+        else {
+          for (int j = 0; j < run; j++) sum += fine[(i << shift) + j];
+          for (int j = 0; j < run; j++) fine[(i << shift) + j] = 0;
+        }
+        bins[i] = sum;
+      }
+    }
+    else for (int i = gid; i < (1 << fine_bits); i += gsz) fine[i] = 0;
+  }
+  else if (bins) for (int i = (int) (b * blockDim.x + threadIdx.x); i < nbins; i += (int) (gridDim.x * blockDim.x)) bins[i] = 0;
   __syncthreads ();
   if (threadIdx.x == 0) { cursors[b] = 0; if (b == 0) { cursors[TJ_P] = TJ_P; fin->n_kept = 0; fin->overflow = 0; fin->pad = 0; } }
 }
@@ -2000,6 +2031,19 @@ __global__ void table_relayout_kernel (const u32 *__restrict__ old, u32 old_maxj
 
 #define BS_MAXBITS   16                  // (bins of the ordering step: see bin_count_kernel)
 __host__ __device__ static inline int cov_table_bits (long n1) { int b = 10; while ((1l << b) < 4 * n1 && b < 31) b++; return b; }   // 2 n1 entries at most: half full
+// The coverage table's keys are flanks cut to 31 bits (src/hopo_counter.c:419-438): with 2k <= 31 there are 4^k of them, and
+// when that is no more than the hash table would have slots the table is addressed by the key itself -- a quarter of the
+// memory to zero and to look through at k = 10, and a plain add instead of a compare-and-swap round trip per record.
+__host__ __device__ static inline int cov_plan_bits (long n1, int k, int *direct)
+{
+  const int hb = cov_table_bits (n1), kb = 2 * k < 31 ? 2 * k : 31;
+  *direct = kb <= hb ? 1 : 0;
+  return kb <= hb ? kb : hb;
+}
+// bins of the finest partition the ordering step can ask for: the aggregation counts its kept records into them as it
+// writes them (the sample's kept count, which decides how many leading bits the step really uses, is not known yet)
+__host__ __device__ static inline int fine_bin_bits (int k) { return BS_MAXBITS < 1 + 4 * k ? BS_MAXBITS : 1 + 4 * k; }
+__device__ __forceinline__ u32 bin_of_record (u64 c0, u64 c1, u64 meta, int k, int nbits);
 __host__ __device__ static inline int bin_bits_for (long n1, int k)
 {
   int nbits = 6;
@@ -2030,7 +2074,8 @@ __device__ __forceinline__ void plan_tail (FinCounts *fin, int k, long cap, FinP
       const u32 ovf = __hip_atomic_load (&fin->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       plan->n1 = n1; plan->kept_overflow = ovf;
       plan->nbits = bin_bits_for (n1, k); plan->nbins = 1 << plan->nbits;
-      plan->log2t = cov_table_bits (n1); plan->t = 1l << plan->log2t;
+      int direct;
+      plan->log2t = cov_plan_bits (n1, k, &direct); plan->t = 1l << plan->log2t; plan->cov_direct = (u32) direct;
       plan->ok = (n1 > 0 && n1 <= cap && !ovf) ? 1 : 0;
       fin->pad = 0;
     }
@@ -2049,7 +2094,7 @@ struct Agg1Lds
 
 __global__ __launch_bounds__ (AG_BLOCK)
 void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin,
-                        long plan_cap, FinPlan *plan)
+                        long plan_cap, FinPlan *plan, u32 *__restrict__ fine, int fine_bits)
 {
   __shared__ Agg1Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2259,7 +2304,10 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     for (int r = 0; r < AG1_S / AG_BLOCK; r++)
       if (metas[r]) {
         const u64 key = L.key[tid + r * AG_BLOCK];
-        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (key >> 32) & 0xFFFFFFull; q[1] = key & 0xFFFFFFull; q[2] = metas[r]; }
+        if (at < kept_cap) {
+          u64 *q = kept + 3 * at; q[0] = (key >> 32) & 0xFFFFFFull; q[1] = key & 0xFFFFFFull; q[2] = metas[r];
+          if (fine) atomicAdd (&fine[bin_of_record ((key >> 32) & 0xFFFFFFull, key & 0xFFFFFFull, metas[r], k, fine_bits)], 1u);
+        }
         else flag_kept_overflow (fin);
         at++;
       }
@@ -2306,7 +2354,7 @@ struct Agg2Lds
 
 __global__ __launch_bounds__ (AG_BLOCK)
 void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin,
-                        long plan_cap, FinPlan *plan)
+                        long plan_cap, FinPlan *plan, u32 *__restrict__ fine, int fine_bits)
 {
   __shared__ Agg2Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2504,7 +2552,10 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     for (int r = 0; r < AG2_S / AG_BLOCK; r++)
       if (metas[r]) {
         const int slot = tid + r * AG_BLOCK;
-        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = (L.kk[slot].x >> 7) & m56; q[1] = L.kk[slot].y & m56; q[2] = metas[r]; }
+        if (at < kept_cap) {
+          u64 *q = kept + 3 * at; q[0] = (L.kk[slot].x >> 7) & m56; q[1] = L.kk[slot].y & m56; q[2] = metas[r];
+          if (fine) atomicAdd (&fine[bin_of_record ((L.kk[slot].x >> 7) & m56, L.kk[slot].y & m56, metas[r], k, fine_bits)], 1u);
+        }
         else flag_kept_overflow (fin);
         at++;
       }
@@ -2539,7 +2590,7 @@ struct Agg4Lds
 
 __global__ __launch_bounds__ (AG_BLOCK)
 void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__restrict__ kept, u64 kept_cap, FinCounts *fin,
-                        long plan_cap, FinPlan *plan)
+                        long plan_cap, FinPlan *plan, u32 *__restrict__ fine, int fine_bits)
 {
   __shared__ Agg4Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2678,7 +2729,10 @@ void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     for (int r = 0; r < AG4_S / AG_BLOCK; r++)
       if (metas[r]) {
         const int slot = tid + r * AG_BLOCK;
-        if (at < kept_cap) { u64 *q = kept + 3 * at; q[0] = L.c0[slot]; q[1] = L.c1[slot]; q[2] = metas[r]; }
+        if (at < kept_cap) {
+          u64 *q = kept + 3 * at; q[0] = L.c0[slot]; q[1] = L.c1[slot]; q[2] = metas[r];
+          if (fine) atomicAdd (&fine[bin_of_record (L.c0[slot], L.c1[slot], metas[r], k, fine_bits)], 1u);
+        }
         else flag_kept_overflow (fin);
         at++;
       }
@@ -2909,9 +2963,11 @@ void bin_scan_kernel (u32 *__restrict__ bins, int nbins, u32 *__restrict__ binst
 
 __global__ __launch_bounds__ (256)
 void bin_scatter_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, long n, int k, int nbits, u32 *__restrict__ cursors,
-                         const FinPlan *__restrict__ plan = nullptr)
+                         const FinPlan *__restrict__ plan = nullptr, uint4 *__restrict__ cov = nullptr)
 {
   if (plan) { if (!plan->ok) return; n = plan->n1; nbits = plan->nbits; }
+  // (no bin_count_kernel ran, see finalise_binned: the coverage table, which the next launch fills, is emptied here)
+  if (cov) for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < plan->t / 2; i += (long) gridDim.x * 256) cov[i] = make_uint4 (0, 0, 0, 0);
   for (long i = (long) blockIdx.x * 256 + threadIdx.x; i < n; i += (long) gridDim.x * 256) {
     const u64 *p = in + 3 * i;
     const u64 a = p[0], b = p[1], m = p[2];
@@ -3031,6 +3087,15 @@ __global__ void ctx_write_kernel (long n1, const u32 *__restrict__ ctxpos, const
 // (wraps like the reference's int, never carries into the key).
 __device__ __forceinline__ u64 cov_word (u32 key31, int w) { return ((u64) (key31 + 1u) << 32) | (u64) (u32) w; }
 
+// The table addressed by the key itself (cov_plan_bits): one 64-bit add per flank.  The low half is the pooled weight (it
+// wraps like the reference's int: the sum of sign-extended weights modulo 2^32); 2^33 per add keeps the high half
+// non-zero for a key that was seen, whatever the weights' signs (|weight| < 2^19), which is all that cov_max_part asks of
+// it (and cannot wrap the word: a flank value is shared by at most 2 x 1024 records' both sides, far from 2^31 adds).
+__device__ __forceinline__ void cov_direct_add (u32 key31, int w, u64 *__restrict__ tab)
+{
+  atomicAdd ((unsigned long long *) &tab[key31], (unsigned long long) (long long) w + (1ull << 33));
+}
+
 __device__ __forceinline__ void cov_add_from (u32 key31, u32 slot, int w, u64 *__restrict__ tab, int log2t)
 {
   const u32 tmask = (1u << log2t) - 1u;
@@ -3129,11 +3194,12 @@ void cov_max_kernel (const u64 *__restrict__ tab, long t, int *result)
 __global__ __launch_bounds__ (64 * BSI_WAVES)
 void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, const u32 *__restrict__ binstart, int nbins, const FinCounts *fin,
                             int min_coverage, u64 *__restrict__ cov_tab, int log2t,
-                            u32 *__restrict__ binctx, u32 *__restrict__ tstart, u32 *__restrict__ tend, const FinPlan *__restrict__ plan = nullptr)
+                            u32 *__restrict__ binctx, u32 *__restrict__ tstart, u32 *__restrict__ tend, const FinPlan *__restrict__ plan = nullptr,
+                            int cov_direct = 0)
 {
   __shared__ u64 rec[BSI_WAVES][3 * BS_RANK_MAX];
   __shared__ u32 hd[BSI_WAVES][BS_RANK_MAX], sz[BSI_WAVES][BS_RANK_MAX];
-  if (plan) { if (!plan->ok) return; nbins = plan->nbins; log2t = plan->log2t; }
+  if (plan) { if (!plan->ok) return; nbins = plan->nbins; log2t = plan->log2t; cov_direct = (int) plan->cov_direct; }
   if (fin->sort_fallback) return;                       // some bin is too full: the caller takes the radix path
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u64 *R = rec[wave];
@@ -3157,8 +3223,9 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
         const int w = meta_count (am);
         // (the coverage table's two compare-and-swaps go out first and are looked at after the ranking: their round trip
         // to memory, a few microseconds, used to be waited for right here)
-        u64 cas_a, cas_b;
-        cov_add2_issue ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
+        u64 cas_a = 0, cas_b = 0;
+        if (cov_direct) { cov_direct_add ((u32) (a0 & 0x7FFFFFFFull), w, cov_tab); cov_direct_add ((u32) (a1 & 0x7FFFFFFFull), w, cov_tab); }
+        else cov_add2_issue ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
         u32 rank = 0, ctx_before = 0, ctx_size = 0;
         int depth = 0;
         for (u32 j = 0; j < s; j++) {
@@ -3173,7 +3240,7 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
         H[t] = rank | (keep ? 0x80000000u : 0u);
         E[t] = ctx_size;
         asm volatile ("" : "+v"(cas_a), "+v"(cas_b));      // (or the compiler tests them for zero, and waits, ahead of the loop)
-        cov_add2_finish ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
+        if (!cov_direct) cov_add2_finish ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
       }
       nkeep += (u32) __popcll (__ballot (keep));
     }
@@ -3433,11 +3500,13 @@ struct tjamd_counter
   u64 raw_bound = 0;          // upper bound of the raw records in the buckets (exact after a synchronisation)
   long n_undefined = 0;
   double slack = 1.0;
-  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov, bins, binstart, binctx, ovf, grp_jt, grp_hist;
+  DevBuf alt, hist, flags, segid, headpos, keep, outpos, scan_tmp, kept, idx_i, idx_f, cov, bins, binstart, binctx, ovf, grp_jt, grp_hist, fine;
   u32 bin_rank_max = BS_RANK_MAX;
   FinCounts *d_fin = nullptr, *h_fin = nullptr;
   struct DevState *d_state = nullptr, *h_state = nullptr;   // ctr, fin and cursors live in one block: one copy brings all three to the host
   bool bins_zeroed = false;
+  bool fine_dirty = false;              // the fine bins hold an aggregation's counts that no clear_buckets_kernel has consumed yet
+  bool bins_counted = false;            // clear_buckets_kernel has turned them into the ordering step's bin counts (finalise_binned: no counting pass)
   long n_kept = 0; int n_idx = 0, coverage = 0, status = -1;
   hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_f0 = nullptr, ev_f1 = nullptr;
   hipEvent_t ev_done = nullptr;                         // tjamd_finalise_begin: the counts have reached the host
@@ -3520,7 +3589,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   (void) hipSetDevice (c->device);
   (void) hipStreamSynchronize (c->stream);
   DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->slow, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
-                   &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx, &c->ovf, &c->grp_jt, &c->grp_hist};
+                   &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx, &c->ovf, &c->grp_jt, &c->grp_hist, &c->fine};
   for (DevBuf *b : all) release (*b);
   for (hipEvent_t ev : c->marks) if (ev) (void) hipEventDestroy (ev);
   if (c->d_state) (void) hipFree (c->d_state);
@@ -3573,14 +3642,18 @@ static Buckets make_buckets (const tjamd_counter *c)
 static int clear_buckets (tjamd_counter *c, bool snapshot = false)
 {
   if (!c->buckets_clean || snapshot) {
+    // (behind an aggregation that counted its kept records into the fine bins: this kernel turns them into the ordering
+    // step's bin counts, see there)
+    const bool fused = snapshot && c->fine_dirty && c->bins.p != nullptr;
     hipLaunchKernelGGL (clear_buckets_kernel, dim3 (TJ_P), dim3 (256), 0, c->stream, c->d_cursors, c->d_ctr,
                         (u32 *) (c->maxj ? c->table.p : nullptr), c->maxj, c->ch_shift, c->d_fin, (u32 *) c->bins.p, c->bins.p ? BS_MAXBINS : 0,
                         snapshot ? &c->d_state->snap_ctr : (DevCounters *) nullptr, snapshot ? c->d_state->snap_cursors : (u32 *) nullptr,
-                        snapshot ? &c->d_state->plan : (FinPlan *) nullptr);
+                        snapshot ? &c->d_state->plan : (FinPlan *) nullptr, fused ? (u32 *) c->fine.p : (u32 *) nullptr, fine_bin_bits (c->k));
     HIPCHK (hipGetLastError ());
     c->buckets_clean = true;
     c->ctr_clean = true;
-    c->bins_zeroed = c->bins.p != nullptr;
+    c->bins_zeroed = c->bins.p != nullptr && !fused;
+    if (fused) { c->fine_dirty = false; c->bins_counted = true; }   // (the fine bins are zeroed again, the step's bins hold its counts if the plan is usable)
   }
   c->n_raw_known = 0; c->raw_bound = 0; c->bucket_bound = 0; c->chunk_bound = TJ_P; c->ch_shift = -1;
   return TJAMD_OK;
@@ -4142,8 +4215,14 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long ca
   if (planned) n1 = cap;                                // (sizes everything below; the kernels use the plan's numbers)
   const int nbits = bin_bits_for (n1, c->k);
   const int nbins = planned ? BS_MAXBINS : 1 << nbits;  // (planned: the layout of binctx / binout must not depend on the count)
-  const int log2t = cov_table_bits (n1);
+  // (planned: the table is allocated for the capacity's hash table, the kernels take their numbers from the plan -- a
+  // table addressed by the key is never larger than that, see cov_plan_bits)
+  int cov_direct = 0;
+  const int log2t = planned ? cov_table_bits (n1) : cov_plan_bits (n1, c->k, &cov_direct);
   const long t = 1l << log2t;
+  // the aggregation has counted the kept records into the finest bins (finalise_impl): no counting pass
+  const bool fused = planned && c->bins_counted;
+  c->bins_counted = false;
   int rc = ensure (c->alt, (size_t) n1 * 24, c->stream);
   if (!rc && !c->bins.p) { rc = ensure (c->bins, (size_t) (BS_MAXBINS + 1) * 4, c->stream); c->bins_zeroed = false; }
   if (!rc) rc = ensure (c->binstart, (size_t) (nbins + 1) * 4, c->stream);
@@ -4157,18 +4236,19 @@ static int finalise_binned (tjamd_counter *c, long n1, int min_coverage, long ca
   u32 *bins = (u32 *) c->bins.p, *binstart = (u32 *) c->binstart.p, *binctx = (u32 *) c->binctx.p, *binout = binctx + nbins;
   u32 *tstart = (u32 *) c->headpos.p, *tend = (u32 *) c->outpos.p;
   u64 *ctab = (u64 *) c->cov.p;
-  if (!c->bins_zeroed) HIPCHK (hipMemsetAsync (bins, 0, (size_t) BS_MAXBINS * 4, c->stream));
+  if (!fused && !c->bins_zeroed) HIPCHK (hipMemsetAsync (bins, 0, (size_t) BS_MAXBINS * 4, c->stream));
   c->bins_zeroed = false;
   if (aside) { HIPCHK (hipEventRecord (c->ev_agg, c->stream)); HIPCHK (hipStreamWaitEvent (st, c->ev_agg, 0)); }
   // (planned: the grids are sized for a typical kept count, not for the buffers' capacity -- the kernels stride)
   const unsigned g1 = planned ? std::min<unsigned> (grid_for (n1), 2048u) : grid_for (n1);
-  hipLaunchKernelGGL (bin_count_kernel, dim3 (g1), dim3 (256), 0, st, (const u64 *) c->kept.p, n1, c->k, nbits, bins,
-                      (uint4 *) c->cov.p, (long) (t / 2), 0, plan);
+  if (!fused) hipLaunchKernelGGL (bin_count_kernel, dim3 (g1), dim3 (256), 0, st, (const u64 *) c->kept.p, n1, c->k, nbits, bins,
+                                  (uint4 *) c->cov.p, (long) (t / 2), 0, plan);
   hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, st, bins, nbins, binstart, c->bin_rank_max, c->d_fin, plan);
-  hipLaunchKernelGGL (bin_scatter_kernel, dim3 (g1), dim3 (256), 0, st, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins, plan);
+  hipLaunchKernelGGL (bin_scatter_kernel, dim3 (g1), dim3 (256), 0, st, (const u64 *) c->kept.p, (u64 *) c->alt.p, n1, c->k, nbits, bins, plan,
+                      fused ? (uint4 *) c->cov.p : (uint4 *) nullptr);
   hipLaunchKernelGGL (bin_sort_index_kernel, dim3 ((unsigned) std::min (nbins / BSI_WAVES + 1, 16384)), dim3 (64 * BSI_WAVES), 0, st,
                       (const u64 *) c->alt.p, (u64 *) c->kept.p, (const u32 *) binstart, nbins, (const FinCounts *) c->d_fin, min_coverage,
-                      ctab, log2t, binctx, tstart, tend, plan);
+                      ctab, log2t, binctx, tstart, tend, plan, cov_direct);
   hipLaunchKernelGGL (bin_ctx_scan_kernel, dim3 (1), dim3 (1024), 0, st, (const u32 *) binctx, nbins, binout, c->d_fin, plan);
   hipLaunchKernelGGL (bin_ctx_write_kernel, dim3 (256), dim3 (256), 0, st, (const u32 *) binstart, (const u32 *) binctx, (const u32 *) binout, nbins,
                       (const u32 *) tstart, (const u32 *) tend, (int *) c->idx_i.p, (int *) c->idx_f.p, (const u64 *) ctab, t, c->d_fin, plan);
@@ -4246,10 +4326,23 @@ static int finalise_impl (tjamd_counter *c, int remove_biased, int min_coverage,
   if (const char *pc = getenv ("TATAJUBA_AMD_PLAN_CAP")) plan_cap = std::max (1l, std::min (plan_cap, atol (pc)));     // (tests: make the second attempt happen)
   plan_ahead = speculative && getenv ("TATAJUBA_AMD_NO_PLAN") == nullptr;
   FinPlan *const d_plan = plan_ahead ? &c->d_state->plan : nullptr;
+  // with the ordering step planned ahead the aggregation counts what it keeps into the finest bins of that step
+  // (clear_buckets_kernel, next on the stream, sums them to the bins the plan asks for and zeroes them again)
+  u32 *fine = nullptr;
+  if (plan_ahead && getenv ("TATAJUBA_AMD_NO_FUSED_BINS") == nullptr) {
+    const bool fresh = c->fine.p == nullptr;
+    rc = ensure (c->fine, (size_t) BS_MAXBINS * 4, c->stream);
+    if (rc) return rc;
+    if (fresh || c->fine_dirty) HIPCHK (hipMemsetAsync (c->fine.p, 0, (size_t) BS_MAXBINS * 4, c->stream));
+    if (!c->bins.p) { rc = ensure (c->bins, (size_t) (BS_MAXBINS + 1) * 4, c->stream); c->bins_zeroed = false; if (rc) return rc; }   // (clear_buckets_kernel writes the step's counts there)
+    fine = (u32 *) c->fine.p;
+    c->fine_dirty = true;
+  }
+  const int fbits = fine_bin_bits (c->k);
   switch (c->W) {
-    case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin, plan_cap, d_plan); break;
-    case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin, plan_cap, d_plan); break;
-    default: hipLaunchKernelGGL (aggregate4_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin, plan_cap, d_plan); break;
+    case 1: hipLaunchKernelGGL (aggregate1_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin, plan_cap, d_plan, fine, fbits); break;
+    case 2: hipLaunchKernelGGL (aggregate2_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin, plan_cap, d_plan, fine, fbits); break;
+    default: hipLaunchKernelGGL (aggregate4_kernel, dim3 (TJ_P), dim3 (AG_BLOCK), 0, c->stream, BK, (u64 *) c->ovf.p, c->k, remove_biased, (u64 *) c->kept.p, kept_cap, c->d_fin, plan_cap, d_plan, fine, fbits); break;
   }
   HIPCHK (hipGetLastError ());
   // counters, bucket sizes and the aggregation's own counts, in one copy; then the buckets are emptied (the aggregation

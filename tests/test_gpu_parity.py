@@ -325,7 +325,7 @@ def test_streams_with_no_calls_match_the_oracle(k, m):
     assert st == 0 and kept > 100
 
 
-@pytest.mark.parametrize("mode", ["plan", "noplan", "cap", "plan+order", "cap+order"])
+@pytest.mark.parametrize("mode", ["plan", "noplan", "cap", "plan+order", "cap+order", "nofuse"])
 def test_finalise_in_two_calls_with_two_counters_on_one_stream(monkeypatch, mode):
     # tjamd_finalise_begin / _end: sample i's outcome is fetched after sample i + 1 has been queued on the same stream
     # "+order": the ordering step of a begun finalise on a second stream (tjamd_counter_set_order_stream), as bench.py runs it
@@ -335,6 +335,8 @@ def test_finalise_in_two_calls_with_two_counters_on_one_stream(monkeypatch, mode
         monkeypatch.setenv("TATAJUBA_AMD_NO_PLAN", "1")
     if mode == "cap":
         monkeypatch.setenv("TATAJUBA_AMD_PLAN_CAP", "300")
+    if mode == "nofuse":                                     # (the ordering step counts its bins itself, as in round 2)
+        monkeypatch.setenv("TATAJUBA_AMD_NO_FUSED_BINS", "1")
     import torch
     streams = [tj.synth_stream(15000 + 3000 * i, 150, 80000, seed_reads=77 + i) for i in range(4)] + [np.frombuffer(b"ACGT\n", np.uint8)]
     devs = [torch.from_numpy(s.copy()).cuda() for s in streams]
