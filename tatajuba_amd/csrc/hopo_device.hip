@@ -939,10 +939,11 @@ struct StageLds
   // three-word formats get 21 KB instead of 16: fewer, fuller partition passes (their fixed cost is per pass), still three
   // workgroups per CU
   static constexpr int WS = (W == 4) ? 3 : W;
-  // BIG = the fast kernel's sink (scan_fast_kernel, two workgroups per CU): one-word records are staged 4096 at a time
-  // (twice the records per pass, runs twice as long), and every array has 64 spare entries so that partition_big can do
-  // without per-record branches
-  static constexpr int WORDS = (W == 1) ? TJ_STAGE_WORDS * (BIG ? 2 : 1) : 2688;
+  // BIG = the fast kernel's sink (scan_fast_kernel, two workgroups per CU): 4096 words of records are staged at a time
+  // (4096 one-word records -- twice the records per pass, runs twice as long -- or 2048 two-word ones: the fast kernel's
+  // LDS budget is the same for every k), and every array has 64 spare entries so that partition_big can do without
+  // per-record branches
+  static constexpr int WORDS = BIG ? TJ_STAGE_WORDS * 2 : (W == 1) ? TJ_STAGE_WORDS : 2688;
   static constexpr int S = WORDS / WS;                   // records
   static constexpr int SPARE = BIG ? 64 : 0;
   u64 rec[WORDS + SPARE * WS];                          // (BIG: slots S + lane take the writes of lanes without a record)
@@ -971,7 +972,7 @@ struct StageSink
   // every round of the pass is full, so it is compiled without the "does this round hold a record" scalar tests (some 130
   // scalar instructions per wave and pass) and without the per-slot "is there a record" selects; what is staged beyond PS
   // (fewer than BLOCK records) moves to the front for the next pass.  PS = 0: no such pass.
-  static constexpr int PS = (BIG && W == 1 && S > BLOCK && (S - BLOCK) % BLOCK == 0) ? S - BLOCK : 0;
+  static constexpr int PS = (BIG && S > BLOCK && (S - BLOCK) % BLOCK == 0) ? S - BLOCK : 0;
   StageLds<W, BIG> &L;
   Buckets B; DevCounters *ctr; int k;
   u32 bound;                                            // upper bound of the records staged (workgroup-uniform)
@@ -1789,6 +1790,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       if (all_fit) sink.bound += (u32) ncand;
       if constexpr (W != 1) {                           // k > 12: two windows per plane (the flanks do not fit one with the tract)
         const long g0 = tile * (long) FK_OWN - FK_HL;
+        const bool n_tile = ncand_all >= 0x40000000u;
         for (int cb0 = 0; cb0 < ncand; cb0 += FK_BLOCK) {
           if (!all_fit) sink.reserve1 ((u32) min (ncand - cb0, FK_BLOCK));   // (may partition)
           if (cb0 + 64 * wave >= ncand) continue;          // (whole waves without a candidate in this round)
@@ -1796,7 +1798,44 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
           bool have = false;
           u64 c0 = 0, c1 = 0;
           u32 base = 0, len10 = 0, flag = 0;
-          if (ci < ncand) have = fast_tract<false> (T, seq, n_bytes, g0, (int) T.cand[ci], k, mprime, c0, c1, base, len10, flag, (ncand_all >= 0x40000000u));
+          if constexpr (W == 2) {
+            // Straight-line path (round 3) for a tract whose k + length + k positions fit one 64-bit window of the planes
+            // -- everything else, rare, goes through fast_tract below -- as in the one-word kernel: lanes past the list's
+            // end redo its last entry and are masked at the end; the run starts from s + 1, the letters and the codes from
+            // s - k are read together (three words each), the right flank's codes behind them once the run's end is known.
+            const bool valid = ci < ncand;
+            const u32 s = T.cand[min (ci, ncand - 1)];
+            const u32 q = s + 1u, u = s - (u32) k;
+            const u32 *ps = &T.st[q >> 5], *pl = &T.lt[u >> 5], *pc = &T.code[u >> 4];
+            u32 s0 = ps[0], s1 = ps[1], s2 = ps[2], l0 = pl[0], l1 = pl[1], l2 = pl[2], w0 = pc[0], w1 = pc[1], w2 = pc[2];
+            asm volatile ("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(w0), "+v"(w1), "+v"(w2));
+            const u64 ns = ((u64) __builtin_amdgcn_alignbit (s2, s1, q) << 32) | __builtin_amdgcn_alignbit (s1, s0, q);
+            const u32 len = (u32) __builtin_ctzll (ns | (1ull << 63)) + 1u;     // (no run start in 64 positions: 64, which does not fit)
+            const int room = 64 - (int) (len + 2u * (u32) k);
+            const bool fits = room >= 0;
+            const u32 rpos = s + (fits ? len : 0u);          // (first position behind the tract; kept inside the planes otherwise)
+            const u32 *pr = &T.code[rpos >> 4];
+            const u32 r0 = pr[0], r1 = pr[1], r2 = pr[2];
+            const u64 notl = ~(((u64) __builtin_amdgcn_alignbit (l2, l1, u) << 32) | __builtin_amdgcn_alignbit (l1, l0, u));
+            const u64 km = kmask (k);
+            const u64 L64 = ((u64) __builtin_amdgcn_alignbit (w2, w1, 2u * u) << 32) | __builtin_amdgcn_alignbit (w1, w0, 2u * u);
+            const u64 R64 = ((u64) __builtin_amdgcn_alignbit (r2, r1, 2u * rpos) << 32) | __builtin_amdgcn_alignbit (r1, r0, 2u * rpos);
+            const u64 left = L64 & km, right = R64 & km;
+            const u32 cb = (u32) (L64 >> (2 * k)) & 3u;      // the tract's base (2k <= 56: inside the window)
+            u64 nl2 = 0, nr2 = 0;
+            if (n_tile) {                                   // (uniform) 'N's in the flanks: forward code 3 where the strand is turned (see fast_tract)
+              const u32 kb32 = (1u << k) - 1u;
+              const u32 nl = bits32 (T.np, (int) u) & kb32, nr = bits32 (T.np, (int) rpos) & kb32;
+              if (nl | nr) { nl2 = spread_pairs (nl); nr2 = spread_pairs (nr); }
+            }
+            const bool rev = cb >= 2u;
+            const u64 rc0 = revcomp_k (right | nr2, k), rc1 = revcomp_k (left | nl2, k);
+            c0 = rev ? rc0 : left; c1 = rev ? rc1 : right;
+            base = rev ? 3u - cb : cb; flag = rev ? 2u : 1u; len10 = len;
+            have = valid && fits && (notl << (room & 63)) == 0ull && (int) len >= mprime;
+            if (valid && !fits) have = fast_tract<false> (T, seq, n_bytes, g0, (int) s, k, mprime, c0, c1, base, len10, flag, n_tile);
+          }
+          else if (ci < ncand) have = fast_tract<false> (T, seq, n_bytes, g0, (int) T.cand[ci], k, mprime, c0, c1, base, len10, flag, n_tile);
           const u64 okm = __builtin_amdgcn_ballot_w64 (have);
           u32 araw;
           lds_add_issue (sink.count_addr (), (u32) __builtin_popcountll (okm), araw);
