@@ -18,13 +18,13 @@ import torch
 
 L = tj.lib()
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-s = tj.synth_stream(n_reads, 150, 5_000_000, n_threads=16)
+s = tj.synth_stream(n_reads, 150, int(os.environ.get("TJ_GENOME", "5000000")), n_threads=16)
 d = torch.from_numpy(s).cuda()
 c = tj.Counter(int(os.environ.get("TJ_K", "10")))
 out = (C.c_ulonglong * 32)()
 for it in range(3):
     c.reset()
-    c.scan_device(d.data_ptr(), s.size, 3)
+    c.scan_device(d.data_ptr(), s.size, int(os.environ.get("TJ_M", "3")))
     c.sync()
     L.tjamd_debug_stamps(out, 1)
 v = np.array(list(out), dtype=np.float64)
