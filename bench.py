@@ -251,6 +251,7 @@ def main():
     if args.rehearse:
         return rehearse(args)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (the host driver supports dmabuf IPC only: RCCL between processes needs it)
     import torch
     import tatajuba_amd as tj
 
