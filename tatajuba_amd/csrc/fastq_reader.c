@@ -129,6 +129,28 @@ tjr_next (tjr_reader *r, const char **seq)
   r->marker_seen = 0;
   r->seq.len = r->qual.len = 0;
   if (tjr_line (r, NULL) < 0) return -1;       /* header line: name and comment are not needed */
+  if (r->in_memory) {
+    /* The usual FASTQ record -- one sequence line, a '+' line, one quality line, all of it inside the block -- without
+     * copying a byte: the sequence is handed out where it lies (the block is the caller's and outlives the call) and the
+     * quality line is only measured.  Everything is looked at before anything is changed; whatever does not fit the
+     * pattern (FASTA, wrapped lines, a record cut by the block's end, a blank line) takes the general path below, which
+     * this one follows step by step: a line loses one trailing '\r' if it is longer than one byte, and the record is
+     * good if the quality line is exactly as long as the sequence. */
+    const unsigned char *b = r->blk, *e = r->blk + r->end, *s0 = b + r->pos, *n1, *n2, *n3;
+    if (s0 < e && *s0 != '>' && *s0 != '+' && *s0 != '@' && *s0 != '\n' &&
+        (n1 = (const unsigned char *) memchr (s0, '\n', (size_t) (e - s0))) != NULL && n1 + 1 < e && n1[1] == '+' &&
+        (n2 = (const unsigned char *) memchr (n1 + 1, '\n', (size_t) (e - n1 - 1))) != NULL && n2 + 1 < e &&
+        (n3 = (const unsigned char *) memchr (n2 + 1, '\n', (size_t) (e - n2 - 1))) != NULL) {
+      size_t ls = (size_t) (n1 - s0), lq = (size_t) (n3 - n2 - 1);
+      if (ls > 1 && n1[-1] == '\r') ls--;
+      if (lq > 1 && n3[-1] == '\r') lq--;
+      if (lq >= ls) {                          /* (a shorter quality line: the general path reads on) */
+        r->pos = (size_t) (n3 - b) + 1;
+        *seq = (const char *) s0;
+        return (lq == ls) ? (long) ls : -2;
+      }
+    }
+  }
   for (;;) {                                   /* sequence lines until a line starts with '+', '>' or '@' */
     c = tjr_byte (r);
     if (c == -1 || c == '>' || c == '+' || c == '@') break;

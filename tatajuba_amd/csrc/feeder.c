@@ -189,13 +189,13 @@ tjf_state_free (tjf_state *s)
  * sent last is still in flight); every fourth window a full synchronisation lets the sink refresh what it knows (exact
  * counts).  Returns != 0 if the sink failed. */
 static int
-tjf_claim_set (tjf_state *s)
+tjf_claim_set (tjf_state *s, int set)
 {
   const tjf_sink *sink = s->sink;
   const double tt = tjf_now ();
   int bad = 0;
   if (sink->mark && sink->wait) {
-    if (s->set_mark[s->set] >= 0 && sink->wait (sink->ctx, s->set_mark[s->set])) bad = 1;
+    if (s->set_mark[set] >= 0 && sink->wait (sink->ctx, s->set_mark[set])) bad = 1;
     else if ((s->n_windows & 3) == 3 && sink->sync && sink->sync (sink->ctx)) bad = 1;
   }
   else if (sink->sync && sink->sync (sink->ctx)) bad = 1;
@@ -251,20 +251,28 @@ tjf_sequential (tjf_state *s, const unsigned char *data, size_t n, size_t start,
 }
 
 /* One window: data[pos, wend) of data[0, n).  whole_file: the bytes are the whole rest of the file (the last range may
- * read past wend); otherwise wend == n is where a view of an unfinished file ends.  Returns the position reached. */
-static size_t
-tjf_window (tjf_state *s, const unsigned char *data, size_t n, size_t pos, size_t wend, int whole_file)
+ * read past wend); otherwise wend == n is where a view of an unfinished file ends.  In three steps, so that a caller with
+ * the whole file in memory can have the next window parsed while this one's batches are handed to the sink
+ * (tjf_parse_file): tjf_win_start (buffer set claimed by the caller, range starts guessed, one reader per range),
+ * tjf_win_join, tjf_win_finish (the chain of ranges checked, their output sent, a wrong guess repaired; returns the
+ * position reached). */
+typedef struct
 {
-  const tjf_sink *sink = s->sink;
-  size_t starts[TJF_MAX_THREADS + 1];
+  const unsigned char *data;
+  size_t n, pos, wend;
+  int whole_file, set, nj;
   tjf_job job[TJF_MAX_THREADS];
   pthread_t th[TJF_MAX_THREADS];
   int started[TJF_MAX_THREADS];
-  int nj = 1, accepted, i, cut = 0, repair = 0;
-  size_t repair_from = 0;
-  double tt;
+  double t_start;
+} tjf_win;
 
-  if (tjf_claim_set (s)) return pos;
+/* all_threads: every range gets a thread of its own (the caller has something else to do until tjf_win_join) */
+static void
+tjf_win_start (tjf_state *s, tjf_win *w, const unsigned char *data, size_t n, size_t pos, size_t wend, int whole_file, int set, int all_threads)
+{
+  size_t starts[TJF_MAX_THREADS + 1];
+  int nj = 1, i;
   starts[0] = pos;
   for (i = 1; i < s->n_threads; i++) {                  /* guessed range starts, strictly increasing */
     const size_t want = pos + (size_t) ((double) (wend - pos) * i / s->n_threads);
@@ -272,17 +280,49 @@ tjf_window (tjf_state *s, const unsigned char *data, size_t n, size_t pos, size_
     if (g > starts[nj - 1] && g < wend) starts[nj++] = g;
   }
   starts[nj] = wend;
-  tt = tjf_now ();
+  w->data = data; w->n = n; w->pos = pos; w->wend = wend; w->whole_file = whole_file; w->set = set; w->nj = nj;
+  w->t_start = tjf_now ();
   for (i = 0; i < nj; i++) {
-    job[i].data = data; job[i].n = n; job[i].start = starts[i]; job[i].stop = starts[i + 1]; job[i].is_last = (i == nj - 1);
-    job[i].open_end = !whole_file;
-    job[i].out = s->buf[s->set][i]; job[i].out_cap = s->cap;
-    started[i] = 0;
-    if (i) { if (pthread_create (&th[i], NULL, tjf_run, &job[i]) == 0) started[i] = 1; else tjf_run (&job[i]); }
+    tjf_job *j = &w->job[i];
+    j->data = data; j->n = n; j->start = starts[i]; j->stop = starts[i + 1]; j->is_last = (i == nj - 1);
+    j->open_end = !whole_file;
+    j->out = s->buf[set][i]; j->out_cap = s->cap;
+    w->started[i] = 0;
+    if (i || all_threads) { if (pthread_create (&w->th[i], NULL, tjf_run, j) == 0) w->started[i] = 1; else tjf_run (j); }
   }
-  tjf_run (&job[0]);
-  for (i = 1; i < nj; i++) if (started[i]) pthread_join (th[i], NULL);
-  s->t_parse += tjf_now () - tt; tt = tjf_now ();
+  if (!all_threads) tjf_run (&w->job[0]);
+}
+
+static void
+tjf_win_join (tjf_state *s, tjf_win *w)
+{
+  int i;
+  for (i = 0; i < w->nj; i++) if (w->started[i]) { pthread_join (w->th[i], NULL); w->started[i] = 0; }
+  s->t_parse += tjf_now () - w->t_start;
+}
+
+/* every range landed on the start of the next and the last one inside the data: the window after this one begins at the
+ * last range's end, whatever the sink makes of this one's batches (a sink that fails ends the file anyway) */
+static int
+tjf_win_plain (const tjf_win *w)
+{
+  int i;
+  for (i = 0; i < w->nj; i++) if (w->job[i].status != TJF_LANDED) return 0;
+  return 1;
+}
+
+static size_t
+tjf_win_finish (tjf_state *s, tjf_win *w)
+{
+  const tjf_sink *sink = s->sink;
+  tjf_job *job = w->job;
+  const unsigned char *data = w->data;
+  const size_t n = w->n, wend = w->wend;
+  size_t pos = w->pos;
+  const int nj = w->nj, whole_file = w->whole_file;
+  int accepted, i, cut = 0, repair = 0;
+  size_t repair_from = 0;
+  double tt = tjf_now ();
 
   accepted = 0;
   for (i = 0; i < nj; i++) {                            /* the chain of ranges: each must end where the next begins */
@@ -298,10 +338,10 @@ tjf_window (tjf_state *s, const unsigned char *data, size_t n, size_t pos, size_
     if (job[i].out_len && sink->put (sink->ctx, job[i].out, job[i].out_len, job[i].n_reads)) { s->done = 1; s->total_reads = -3; break; }
     s->total_reads += job[i].n_reads;
   }
-  if (s->total_reads >= 0 && sink->mark) { s->set_mark[s->set] = sink->mark (sink->ctx); if (s->set_mark[s->set] < 0) s->total_reads = -3; }
+  if (s->total_reads >= 0 && sink->mark) { s->set_mark[w->set] = sink->mark (sink->ctx); if (s->set_mark[w->set] < 0) s->total_reads = -3; }
   s->t_put += tjf_now () - tt;
   if (s->total_reads < 0) { s->done = 1; return pos; }
-  s->set ^= 1;                                          /* (the set just sent is in flight) */
+  s->set = w->set ^ 1;                                  /* (the set just sent is in flight) */
   if (s->done) return n;
   if (cut) return job[accepted - 1].end_pos;
   if (repair) {                                         /* a wrong guess: one reader for the rest of this window */
@@ -314,6 +354,16 @@ tjf_window (tjf_state *s, const unsigned char *data, size_t n, size_t pos, size_
     return pos;
   }
   return job[nj - 1].end_pos;
+}
+
+static size_t
+tjf_window (tjf_state *s, const unsigned char *data, size_t n, size_t pos, size_t wend, int whole_file)
+{
+  tjf_win w;
+  if (tjf_claim_set (s, s->set)) return pos;
+  tjf_win_start (s, &w, data, n, pos, wend, whole_file, s->set, 0);
+  tjf_win_join (s, &w);
+  return tjf_win_finish (s, &w);
 }
 
 static void
@@ -358,9 +408,37 @@ tjf_parse_file (const char *path, int n_threads, size_t window_bytes, const tjf_
   if (window_bytes < 4096) window_bytes = 4096;
   tjf_stat_windows = 0; tjf_stat_fallback = 0; tjf_stat_bgzf = 0;
   if (tjf_state_init (&s, sink, n_threads, window_bytes)) { tjf_state_free (&s); munmap ((void *) data, n); return -2; }
-  while (!s.done && pos < n) {
-    const size_t wend = (n - pos > window_bytes) ? pos + window_bytes : n;
-    pos = tjf_window (&s, data, n, pos, wend, 1);
+  {
+    /* Two windows in turn: while the batches of one go to the sink (copies and kernel launches queued by this thread,
+     * a fifth of the file's time), the readers are already on the next -- whose start is the end of this one's last range
+     * as soon as every range has landed on the next one's start, which is known before anything is sent.  Anything else
+     * (a wrong guess to repair, the end of the file, a bad quality line) is finished first, as in tjf_window. */
+    tjf_win *w = (tjf_win *) malloc (2 * sizeof (tjf_win));
+    int cur = 0, have = 0;
+    if (!w) { tjf_state_free (&s); munmap ((void *) data, n); return -2; }
+    while (!s.done && (have || pos < n)) {
+      int ahead = 0;
+      if (!have) {
+        const size_t wend = (n - pos > window_bytes) ? pos + window_bytes : n;
+        if (tjf_claim_set (&s, s.set)) break;
+        tjf_win_start (&s, &w[cur], data, n, pos, wend, 1, s.set, 1);
+      }
+      tjf_win_join (&s, &w[cur]);
+      have = 0;
+      if (tjf_win_plain (&w[cur])) {
+        const size_t npos = w[cur].job[w[cur].nj - 1].end_pos;
+        if (npos < n) {
+          const size_t wend = (n - npos > window_bytes) ? npos + window_bytes : n;
+          if (tjf_claim_set (&s, w[cur].set ^ 1)) break;                  /* (waits for the batches sent from that set two windows ago) */
+          tjf_win_start (&s, &w[cur ^ 1], data, n, npos, wend, 1, w[cur].set ^ 1, 1);
+          ahead = 1;
+        }
+      }
+      pos = tjf_win_finish (&s, &w[cur]);
+      if (ahead) { have = 1; cur ^= 1; }
+    }
+    if (have) tjf_win_join (&s, &w[cur]);               /* (the sink failed: the readers that are under way are waited for, their output dropped) */
+    free (w);
   }
   if (sink->sync) (void) sink->sync (sink->ctx);
   tjf_state_free (&s);
