@@ -3237,7 +3237,8 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
                             int cov_direct = 0)
 {
   __shared__ u64 rec[BSI_WAVES][3 * BS_RANK_MAX];
-  __shared__ u32 hd[BSI_WAVES][BS_RANK_MAX], sz[BSI_WAVES][BS_RANK_MAX];
+  __shared__ alignas (16) u32 hd[BSI_WAVES][BS_RANK_MAX];
+  __shared__ u32 sz[BSI_WAVES][BS_RANK_MAX];
   if (plan) { if (!plan->ok) return; nbins = plan->nbins; log2t = plan->log2t; cov_direct = (int) plan->cov_direct; }
   if (fin->sort_fallback) return;                       // some bin is too full: the caller takes the radix path
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -3267,11 +3268,30 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
         else cov_add2_issue ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
         u32 rank = 0, ctx_before = 0, ctx_size = 0;
         int depth = 0;
-        for (u32 j = 0; j < s; j++) {
-          const u64 b0 = R[3 * j], b1 = R[3 * j + 1], bm = R[3 * j + 2];
-          const bool before = record_before (b0, b1, bm, j, a0, a1, am, t);
-          rank += before ? 1u : 0u;
-          if (b0 == a0 && b1 == a1 && ((bm ^ am) & 3ull) == 0ull) { ctx_size++; depth += meta_count (bm); ctx_before += before ? 1u : 0u; }
+        // (the bin's records four at a time, the same for every lane: twelve LDS reads in flight for one wait, and the
+        // comparison -- record_before, spelt without branches -- is a chain of lane masks: as nested ifs, one record per turn,
+        // it was four exec regions and a wait for the reads in every turn, 220 cycles for 30 instructions)
+        const u32 abase = (u32) am & 1u, alen = ((u32) (am >> TJ_META_LEN_SHIFT) & 0x3FFu) ^ 0x200u;
+        for (u32 j0 = 0; j0 < s; j0 += 4) {
+          u64 b0[4], b1[4], bm[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const u32 jj = (j0 + (u32) i < s) ? j0 + (u32) i : s - 1u;
+            b0[i] = R[3 * jj]; b1[i] = R[3 * jj + 1]; bm[i] = R[3 * jj + 2];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const u32 j = j0 + (u32) i;
+            const bool live = j < s;                        // (uniform)
+            const u32 bbase = (u32) bm[i] & 1u, blen = ((u32) (bm[i] >> TJ_META_LEN_SHIFT) & 0x3FFu) ^ 0x200u;
+            const bool e0 = b0[i] == a0, e1 = b1[i] == a1, eb = bbase == abase;
+            const bool before = live & ((bbase > abase) | (eb & ((b0[i] > a0) | (e0 & ((b1[i] > a1) | (e1 & ((blen > alen) | ((blen == alen) & (j < t)))))))));
+            const bool same = live & e0 & e1 & (((u32) (bm[i] ^ am) & 3u) == 0u);
+            rank += before ? 1u : 0u;
+            ctx_size += same ? 1u : 0u;
+            depth += same ? meta_count (bm[i]) : 0;
+            ctx_before += (same & before) ? 1u : 0u;
+          }
         }
         u64 *q = out + 3 * ((u64) st + rank);
         q[0] = a0; q[1] = a1; q[2] = am;
@@ -3290,7 +3310,13 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
       if (h & 0x80000000u) {
         const u32 rank = h & 0x7FFFFFFFu;
         u32 o = 0;
-        for (u32 j = 0; j < s; j++) { const u32 g = H[j]; o += ((g & 0x80000000u) && (g & 0x7FFFFFFFu) < rank) ? 1u : 0u; }
+        for (u32 j = 0; j < s; j += 4) {                  // (four entries per LDS read; entries past the bin's end hold an earlier bin's)
+          const uint4 g = *reinterpret_cast<const uint4 *> (&H[j]);
+          o += ((g.x & 0x80000000u) && (g.x & 0x7FFFFFFFu) < rank) ? 1u : 0u;
+          o += (j + 1u < s && (g.y & 0x80000000u) && (g.y & 0x7FFFFFFFu) < rank) ? 1u : 0u;
+          o += (j + 2u < s && (g.z & 0x80000000u) && (g.z & 0x7FFFFFFFu) < rank) ? 1u : 0u;
+          o += (j + 3u < s && (g.w & 0x80000000u) && (g.w & 0x7FFFFFFFu) < rank) ? 1u : 0u;
+        }
         tstart[st + o] = st + rank;
         tend[st + o] = st + rank + E[t];
       }
