@@ -3399,7 +3399,7 @@ void bin_merge_kernel (const u64 *__restrict__ rec, const u32 *__restrict__ bins
                        u32 *__restrict__ binctx, u32 *__restrict__ tpos, u32 *__restrict__ ttot)
 {
   __shared__ u64 R[3 * MG_RANK_MAX];
-  __shared__ u32 H[MG_RANK_MAX];                        // records in front of this one's key | representative << 31
+  __shared__ alignas (16) u32 H[MG_RANK_MAX];           // records in front of this one's key | representative << 31
   if (fin->sort_fallback) return;
   const int lane = threadIdx.x;
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
@@ -3422,12 +3422,25 @@ void bin_merge_kernel (const u64 *__restrict__ rec, const u32 *__restrict__ bins
         const u64 a0 = R[3 * t], a1 = R[3 * t + 1], al = R[3 * t + 2] & lmask;
         rep = true;
         u32 tot = 0, r = 0, fl = 0;
-        for (u32 j = 0; j < s; j++) {
-          const u64 b0 = R[3 * j], b1 = R[3 * j + 1], bm = R[3 * j + 2], bl = bm & lmask;
-          const bool same = (b0 == a0) & (b1 == a1) & (bl == al);
-          const bool before = (b0 > a0) | ((b0 == a0) & ((b1 > a1) | ((b1 == a1) & (bl > al))));
-          r += before ? 1u : 0u;
-          if (same) { if (j < t) rep = false; tot += (u32) meta_count (bm); fl |= (u32) (bm >> TJ_META_FLAG_SHIFT) & 7u; }
+        for (u32 j0 = 0; j0 < s; j0 += 4) {               // (four records per turn of LDS reads, no branch: see bin_sort_index_kernel)
+          u64 b0[4], b1[4], bm[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const u32 jj = (j0 + (u32) i < s) ? j0 + (u32) i : s - 1u;
+            b0[i] = R[3 * jj]; b1[i] = R[3 * jj + 1]; bm[i] = R[3 * jj + 2];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const u32 j = j0 + (u32) i;
+            const bool live = j < s;                        // (uniform)
+            const u64 bl = bm[i] & lmask;
+            const bool same = live & (b0[i] == a0) & (b1[i] == a1) & (bl == al);
+            const bool before = live & ((b0[i] > a0) | ((b0[i] == a0) & ((b1[i] > a1) | ((b1[i] == a1) & (bl > al)))));
+            r += before ? 1u : 0u;
+            rep = rep & !(same & (j < t));
+            tot += same ? (u32) meta_count (bm[i]) : 0u;
+            fl |= same ? (u32) (bm[i] >> TJ_META_FLAG_SHIFT) & 7u : 0u;
+          }
         }
         H[t] = r | (rep ? 0x80000000u : 0u);
         // (the key's depth over all samples, 20-bit store, and the strands any sample saw it on)
@@ -3440,7 +3453,13 @@ void bin_merge_kernel (const u64 *__restrict__ rec, const u32 *__restrict__ bins
     for (u32 t = lane; t < s; t += 64) {                // pass 2: distinct keys in front = representatives with fewer records in front
       const u32 r = H[t] & 0x7FFFFFFFu;
       u32 d = 0;
-      for (u32 j = 0; j < s; j++) { const u32 h = H[j]; d += ((h & 0x80000000u) && (h & 0x7FFFFFFFu) < r) ? 1u : 0u; }
+      for (u32 j = 0; j < s; j += 4) {                    // (four entries per LDS read; entries past the bin's end hold an earlier bin's)
+        const uint4 h = *reinterpret_cast<const uint4 *> (&H[j]);
+        d += ((h.x & 0x80000000u) && (h.x & 0x7FFFFFFFu) < r) ? 1u : 0u;
+        d += (j + 1u < s && (h.y & 0x80000000u) && (h.y & 0x7FFFFFFFu) < r) ? 1u : 0u;
+        d += (j + 2u < s && (h.z & 0x80000000u) && (h.z & 0x7FFFFFFFu) < r) ? 1u : 0u;
+        d += (j + 3u < s && (h.w & 0x80000000u) && (h.w & 0x7FFFFFFFu) < r) ? 1u : 0u;
+      }
       tpos[st + t] = d;
     }
     if (lane == 0) binctx[bin] = nrep;

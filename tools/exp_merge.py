@@ -2,6 +2,10 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import tatajuba_amd.build as B
+B._SO = os.path.join(ROOT, "tatajuba_amd", os.environ.get("TJ_DIAG_LIB", "libtatajuba_amd.so"))
+import tatajuba_amd.capi as capi
+capi.library_path = lambda: B._SO
 import numpy as np, torch
 import tatajuba_amd as tj
 from tatajuba_amd.dist import device_bytes_tensor, merge_histograms_device
