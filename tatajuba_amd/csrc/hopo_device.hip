@@ -3588,6 +3588,7 @@ struct tjamd_counter
   u32 bin_rank_max = BS_RANK_MAX;
   FinCounts *d_fin = nullptr, *h_fin = nullptr;
   struct DevState *d_state = nullptr, *h_state = nullptr;   // ctr, fin and cursors live in one block: one copy brings all three to the host
+  void *h_kept = nullptr; size_t h_kept_cap = 0;   // pinned landing place of tjamd_download_kept (grown, never per call)
   bool bins_zeroed = false;
   bool fine_dirty = false;              // the fine bins hold an aggregation's counts that no clear_buckets_kernel has consumed yet
   bool bins_counted = false;            // clear_buckets_kernel has turned them into the ordering step's bin counts (finalise_binned: no counting pass)
@@ -3679,6 +3680,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   if (c->d_state) (void) hipFree (c->d_state);
   if (c->d_lctr) (void) hipFree (c->d_lctr);
   if (c->h_state) (void) hipHostFree (c->h_state);
+  if (c->h_kept) (void) hipHostFree (c->h_kept);
   if (c->ev_s0) (void) hipEventDestroy (c->ev_s0);
   if (c->ev_s1) (void) hipEventDestroy (c->ev_s1);
   if (c->ev_f0) (void) hipEventDestroy (c->ev_f0);
@@ -4496,8 +4498,18 @@ extern "C" long tjamd_download_kept (tjamd_counter *c, hopo_element *out, long c
   if (n1 > capacity) return -set_err (TJAMD_ERR_CAPACITY, "%ld kept records, caller capacity %ld", n1, capacity);
   if (n1 == 0) return 0;
   if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
-  std::vector<tjamd_record> tmp ((size_t) n1);
-  if (hipMemcpy (tmp.data (), c->kept.p, (size_t) n1 * 24, hipMemcpyDeviceToHost) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "download failed");
+  // (into pinned memory that the counter keeps: a fresh pageable vector of n1 records cost its page faults and a staged
+  // copy every time -- a third of what finalise_hopo_counter spends behind the device finalise)
+  if ((size_t) n1 * 24 > c->h_kept_cap) {
+    if (c->h_kept) (void) hipHostFree (c->h_kept);
+    c->h_kept = nullptr; c->h_kept_cap = 0;
+    const size_t want = (size_t) n1 * 24 + ((size_t) n1 * 24 >> 2) + 4096;
+    if (hipHostMalloc (&c->h_kept, want, hipHostMallocDefault) != hipSuccess) { c->h_kept = nullptr; return -set_err (TJAMD_ERR_HIP, "hipHostMalloc of %zu bytes failed", want); }
+    c->h_kept_cap = want;
+  }
+  const tjamd_record *tmp = (const tjamd_record *) c->h_kept;
+  if (hipMemcpyAsync (c->h_kept, c->kept.p, (size_t) n1 * 24, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "download failed");
   for (long i = 0; i < n1; i++) {
     out[i].context[0] = tmp[i].ctx0; out[i].context[1] = tmp[i].ctx1;
     memcpy ((char *) &out[i] + 16, &tmp[i].meta, 8);
