@@ -3128,8 +3128,9 @@ __device__ __forceinline__ u64 cov_word (u32 key31, int w) { return ((u64) (key3
 
 // The table addressed by the key itself (cov_plan_bits): one 64-bit add per flank.  The low half is the pooled weight (it
 // wraps like the reference's int: the sum of sign-extended weights modulo 2^32); 2^33 per add keeps the high half
-// non-zero for a key that was seen, whatever the weights' signs (|weight| < 2^19), which is all that cov_max_part asks of
-// it (and cannot wrap the word: a flank value is shared by at most 2 x 1024 records' both sides, far from 2^31 adds).
+// non-zero for a key that was seen, whatever the weights' signs (|weight| < 2^30: a context's depth, the sum of at most
+// 1024 counts of 20 bits), which is all that cov_max_part asks of it (and cannot wrap the word: a flank value is shared by
+// at most 2 x 1024 records' both sides, far from 2^31 adds).
 __device__ __forceinline__ void cov_direct_add (u32 key31, int w, u64 *__restrict__ tab)
 {
   atomicAdd ((unsigned long long *) &tab[key31], (unsigned long long) (long long) w + (1ull << 33));
@@ -3230,42 +3231,136 @@ void cov_max_kernel (const u64 *__restrict__ tab, long t, int *result)
 //   tstart/tend[st+o]  index range of the o-th such context of the bin (st = first record of the bin)
 #define BSI_WAVES 1
 
+// the value that lane (lane ^ J) holds, without the LDS pipe: quad permutes for 1 and 2, a row shift either way for 4 and 8,
+// gfx950's row and half swaps for 16 and 32 (a ds_bpermute per word and step kept the LDS pipe busy for half of the sort
+// kernel's time: 168 of them per bin)
+template <int J>
+__device__ __forceinline__ u32 lane_xor (u32 v, int lane)
+{
+  if constexpr (J == 1) return (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  else if constexpr (J == 4 || J == 8) {
+    const u32 up = (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x100 + J, 0xF, 0xF, false);               // row_shl: lane i gets lane i + J
+    const u32 dn = (u32) __builtin_amdgcn_update_dpp (0, (int) v, 0x110 + J, 0xF, 0xF, false);               // row_shr: lane i gets lane i - J
+    return (lane & J) ? dn : up;
+  }
+  else if constexpr (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap (v, v, false, false); return (lane & 16) ? r[0] : r[1]; }
+  else { const auto r = __builtin_amdgcn_permlane32_swap (v, v, false, false); return (lane & 32) ? r[0] : r[1]; }
+}
+
 __global__ __launch_bounds__ (64 * BSI_WAVES)
 void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, const u32 *__restrict__ binstart, int nbins, const FinCounts *fin,
                             int min_coverage, u64 *__restrict__ cov_tab, int log2t,
                             u32 *__restrict__ binctx, u32 *__restrict__ tstart, u32 *__restrict__ tend, const FinPlan *__restrict__ plan = nullptr,
                             int cov_direct = 0)
 {
-  __shared__ u64 rec[BSI_WAVES][3 * BS_RANK_MAX];
+  // (2 KB of LDS per wavefront: the usual bin lives in registers, a fuller one reads its records where they lie -- with the
+  // records of up to 256 staged in LDS, 8 KB, twenty wavefronts fitted a CU instead of twenty-eight, and a wavefront's
+  // time is a chain of memory round trips that only other wavefronts can fill)
   __shared__ alignas (16) u32 hd[BSI_WAVES][BS_RANK_MAX];
   __shared__ u32 sz[BSI_WAVES][BS_RANK_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the first bin's bounds are asked for together with the plan: one round trip less in the chain; `nbins` as passed is
+  // the layout's size, which the array has whatever the plan says)
+  const int bin0 = (int) blockIdx.x * BSI_WAVES + wave;
+  u32 st0 = 0, en0 = 0;
+  if (bin0 < nbins) { st0 = binstart[bin0]; en0 = binstart[bin0 + 1]; }
   if (plan) { if (!plan->ok) return; nbins = plan->nbins; log2t = plan->log2t; cov_direct = (int) plan->cov_direct; }
   if (fin->sort_fallback) return;                       // some bin is too full: the caller takes the radix path
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  u64 *R = rec[wave];
   u32 *H = hd[wave], *E = sz[wave];
-  for (int bin = blockIdx.x * BSI_WAVES + wave; bin < nbins; bin += gridDim.x * BSI_WAVES) {
-    const u32 st = binstart[bin], s = binstart[bin + 1] - st;
+  for (int bin = bin0; bin < nbins; bin += gridDim.x * BSI_WAVES) {
+    const u32 st = (bin == bin0) ? st0 : binstart[bin], s = ((bin == bin0) ? en0 : binstart[bin + 1]) - st;
     if (s == 0) { if (lane == 0) binctx[bin] = 0; continue; }
-    for (u32 t = lane; t < s; t += 64) {                // one record per lane: its three loads are in flight together
-      const u64 *p = in + 3 * (u64) (st + t);
-      const u64 v0 = p[0], v1 = p[1], v2 = p[2];
-      R[3 * t] = v0; R[3 * t + 1] = v1; R[3 * t + 2] = v2;
-    }
-    asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // wave-private LDS: in-order, only the data must have landed
-    __builtin_amdgcn_wave_barrier ();
+    const u64 *R = in + 3 * (u64) st;                   // the bin's records (a fuller bin reads them from here, the same record in every lane)
     u32 nkeep = 0;
+    if (s <= 64u) {
+      // The usual bin (a record per lane at most): a bitonic sort of the records across the wavefront's lanes -- 21
+      // compare-and-exchange steps of some thirty instructions -- instead of every lane comparing its record with every
+      // record of the bin (s / 4 turns of 180); sorted, a record's place is its lane, a context's records are neighbours,
+      // and its size, depth and place among the contexts that are kept come out of two ballots and one prefix sum.
+      const bool valid = (u32) lane < s;
+      u64 a0 = 0, a1 = 0, am = 0;
+      if (valid) { a0 = R[3 * lane]; a1 = R[3 * lane + 1]; am = R[3 * lane + 2]; }   // (one record per lane: its three loads are in flight together)
+      // (a hashed coverage table: the record's two compare-and-swaps go out now and are looked at after the sort -- their round
+      // trip to memory, a few microseconds, runs under it, and they stay with the lane that sent them.  Tried: reading the two
+      // home slots first and adding where the key is already there, one atomic per flank instead of two -- no change, 177
+      // against 179 us on the long-read sample: it is the random 8-byte accesses to a 64 MB table that this kernel waits for
+      // there, whatever their kind)
+      const int w = meta_count (am);
+      u64 cas_a = 0, cas_b = 0;
+      if (!cov_direct && valid) cov_add2_issue ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
+      // order: records before empty lanes, then base, ctx0, ctx1, signed length, all descending (record_before); kh holds
+      // what comes before the contexts, kl what comes after them (a lane's own number last: no two lanes compare equal)
+      u32 kh = valid ? 2u | ((u32) am & 1u) : 0u;
+      u32 kl = ((((u32) (am >> TJ_META_LEN_SHIFT) & 0x3FFu) ^ 0x200u) << 6) | (63u - (u32) lane);
+      u32 x0 = (u32) a0, x1 = (u32) (a0 >> 32), y0 = (u32) a1, y1 = (u32) (a1 >> 32), m0 = (u32) am, m1 = (u32) (am >> 32);
+      auto step = [&] (auto jc, int kk) {
+        constexpr int J = decltype (jc)::value;
+        const u32 ox0 = lane_xor<J> (x0, lane), ox1 = lane_xor<J> (x1, lane), oy0 = lane_xor<J> (y0, lane), oy1 = lane_xor<J> (y1, lane);
+        const u32 om0 = lane_xor<J> (m0, lane), om1 = lane_xor<J> (m1, lane), okh = lane_xor<J> (kh, lane), okl = lane_xor<J> (kl, lane);
+        const u64 mx = ((u64) x1 << 32) | x0, my = ((u64) y1 << 32) | y0, ox = ((u64) ox1 << 32) | ox0, oy = ((u64) oy1 << 32) | oy0;
+        const bool mine_first = (kh > okh) | ((kh == okh) & ((mx > ox) | ((mx == ox) & ((my > oy) | ((my == oy) & (kl > okl))))));
+        // the lower lane of a pair keeps the record that comes first where the run of kk lanes is to ascend, the other one where it is to descend
+        const bool want_first = ((lane & kk) == 0) == ((lane & J) == 0);
+        const bool take = mine_first != want_first;       // the partner's record
+        x0 = take ? ox0 : x0; x1 = take ? ox1 : x1; y0 = take ? oy0 : y0; y1 = take ? oy1 : y1;
+        m0 = take ? om0 : m0; m1 = take ? om1 : m1; kh = take ? okh : kh; kl = take ? okl : kl;
+      };
+#pragma unroll
+      for (int kk = 2; kk <= 64; kk <<= 1) {
+        if (kk >= 64) step (std::integral_constant<int, 32> (), kk);
+        if (kk >= 32) step (std::integral_constant<int, 16> (), kk);
+        if (kk >= 16) step (std::integral_constant<int, 8> (), kk);
+        if (kk >= 8) step (std::integral_constant<int, 4> (), kk);
+        if (kk >= 4) step (std::integral_constant<int, 2> (), kk);
+        step (std::integral_constant<int, 1> (), kk);
+      }
+      // lane i holds the i-th record of the bin
+      const bool have = kh >= 2u;                          // (the records are in lanes 0 .. s - 1 again)
+      const u64 b0 = ((u64) x1 << 32) | x0, b1 = ((u64) y1 << 32) | y0, bm = ((u64) m1 << 32) | m0;
+      if (have) { u64 *q = out + 3 * ((u64) st + (u32) lane); q[0] = b0; q[1] = b1; q[2] = bm; }
+      // a context's first record: the lane before holds another context (or it is lane 0)
+      const u32 px0 = (u32) __builtin_amdgcn_update_dpp (0, (int) x0, 0x138, 0xF, 0xF, false), px1 = (u32) __builtin_amdgcn_update_dpp (0, (int) x1, 0x138, 0xF, 0xF, false);
+      const u32 py0 = (u32) __builtin_amdgcn_update_dpp (0, (int) y0, 0x138, 0xF, 0xF, false), py1 = (u32) __builtin_amdgcn_update_dpp (0, (int) y1, 0x138, 0xF, 0xF, false);
+      const u32 pkh = (u32) __builtin_amdgcn_update_dpp (0, (int) kh, 0x138, 0xF, 0xF, false);
+      const bool head = have & ((lane == 0) | (px0 != x0) | (px1 != x1) | (py0 != y0) | (py1 != y1) | (pkh != kh));
+      const u64 heads = __ballot (head);
+      const int cnt = have ? meta_count (bm) : 0;
+      const u32 incl = wave_inclusive_scan ((u32) cnt);    // (wraps like the int sum it stands for)
+      const u64 above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+      const u32 next_head = above ? (u32) lane + (u32) __ffsll ((long long) above) : s;   // first lane of the next context (or the end)
+      const u32 last_incl = (u32) __builtin_amdgcn_ds_bpermute ((int) ((next_head - 1u) << 2), (int) incl);
+      const int depth = (int) (last_incl - (incl - (u32) cnt));
+      const bool keep = head & (depth >= min_coverage);
+      const u64 keeps = __ballot (keep);
+      if (keep) {
+        const u32 o = (u32) __popcll (keeps & ((1ull << lane) - 1ull));
+        tstart[st + o] = st + (u32) lane;
+        tend[st + o] = st + next_head;
+      }
+      nkeep = (u32) __popcll (keeps);
+      // The coverage table takes a context's records in one go: they pool under the same two flanks, so the context's depth
+      // is added once for each (the sum of the counts, wrapping like the reference's int, whatever the order) -- the
+      // memory-side atomics are what this kernel runs at (24 G/s whatever the addresses: 470 k adds were 20 of its 31 us on
+      // the headline sample), and a context has 2.3 records on average.
+      // (only where the table is addressed by the flank itself: a plain add needs no answer)
+      if (cov_direct) {
+        if (head) { cov_direct_add ((u32) (b0 & 0x7FFFFFFFull), depth, cov_tab); cov_direct_add ((u32) (b1 & 0x7FFFFFFFull), depth, cov_tab); }
+      }
+      else if (valid) {
+        asm volatile ("" : "+v"(cas_a), "+v"(cas_b));      // (or the compiler tests them for zero, and waits, ahead of the sort)
+        cov_add2_finish ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
+      }
+      if (lane == 0) binctx[bin] = nkeep;
+      asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier ();
+      continue;
+    }
     for (u32 t0 = 0; t0 < s; t0 += 64) {
       const u32 t = t0 + lane;
       bool keep = false;
       if (t < s) {
         const u64 a0 = R[3 * t], a1 = R[3 * t + 1], am = R[3 * t + 2];
-        const int w = meta_count (am);
-        // (the coverage table's two compare-and-swaps go out first and are looked at after the ranking: their round trip
-        // to memory, a few microseconds, used to be waited for right here)
-        u64 cas_a = 0, cas_b = 0;
-        if (cov_direct) { cov_direct_add ((u32) (a0 & 0x7FFFFFFFull), w, cov_tab); cov_direct_add ((u32) (a1 & 0x7FFFFFFFull), w, cov_tab); }
-        else cov_add2_issue ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
         u32 rank = 0, ctx_before = 0, ctx_size = 0;
         int depth = 0;
         // (the bin's records four at a time, the same for every lane: twelve LDS reads in flight for one wait, and the
@@ -3298,8 +3393,10 @@ void bin_sort_index_kernel (const u64 *__restrict__ in, u64 *__restrict__ out, c
         keep = (ctx_before == 0u) && depth >= min_coverage;      // first record of its context, context deep enough
         H[t] = rank | (keep ? 0x80000000u : 0u);
         E[t] = ctx_size;
-        asm volatile ("" : "+v"(cas_a), "+v"(cas_b));      // (or the compiler tests them for zero, and waits, ahead of the loop)
-        if (!cov_direct) cov_add2_finish ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), w, cov_tab, log2t, cas_a, cas_b);
+        if (ctx_before == 0u) {                            // (the context's depth, once for each flank: see above)
+          if (cov_direct) { cov_direct_add ((u32) (a0 & 0x7FFFFFFFull), depth, cov_tab); cov_direct_add ((u32) (a1 & 0x7FFFFFFFull), depth, cov_tab); }
+          else cov_add2 ((u32) (a0 & 0x7FFFFFFFull), (u32) (a1 & 0x7FFFFFFFull), depth, cov_tab, log2t);
+        }
       }
       nkeep += (u32) __popcll (__ballot (keep));
     }
