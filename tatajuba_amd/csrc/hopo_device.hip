@@ -106,7 +106,7 @@ struct DevCounters
   // (no memset between launches)
   // work = tile counter of the main scan kernel of the launch; n_slow = tiles the fast kernel handed to the generic one
   // (stream edges, bytes outside ACGT\n, too many candidates); work_slow = the generic kernel's counter over that list
-  struct { u64 n_fix; u32 work, n_slow, work_slow, pad[3]; } lc[2];
+  struct { u64 n_fix; u32 work, n_slow, work_slow, ticket, pad[2]; } lc[2];   // (ticket: workgroups of the generic kernel that are through, see scan_bins_kernel)
 };
 
 #ifndef TJ_TILE_GROUP
@@ -467,7 +467,7 @@ __device__ __forceinline__ void scan_tiles (const uint8_t *__restrict__ seq, lon
   // how many tracts their tiles hold, and a static split leaves the slow ones running alone at the end.
   if (tid == 0) {
     T.odd[0] = 0; T.odd[1] = 0; T.grp[0] = atomicAdd (work, tgroup);
-    if (blockIdx.x == 0 && !listed) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; }
+    if (blockIdx.x == 0 && !listed) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; ctr->lc[par ^ 1].ticket = 0; }
   }
   lds_barrier ();
   long tile = (long) T.grp[0];
@@ -1320,6 +1320,22 @@ struct StageSink
 #define TJ_SB_WG_PER_CU 3               // grid = 3 workgroups per CU: 2 are resident (65 KB of LDS each), the queued third evens out the tail
 #endif
 
+// the qualifying runs of a non-ACGTU byte that scan_tiles has listed: their context is the tract before them (reference
+// src/hopo_counter.c:246-248).  Entries first, first + step, ...
+template <int W>
+__device__ __forceinline__ void nrun_fixup_entries (const uint8_t *__restrict__ seq, long n_bytes, int k, int mprime, Buckets BK, DevCounters *ctr,
+                                                    const FixEntry *fix, u32 fix_cap, int par, u64 first, u64 step)
+{
+  u64 n_fix = __hip_atomic_load (&ctr->lc[par].n_fix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (n_fix > fix_cap) n_fix = fix_cap;
+  for (u64 i = first; i < n_fix; i += step) {
+    u64 c0, c1; u32 base, flag;
+    if (stale_context (seq, n_bytes, fix[i].pos, k, mprime, c0, c1, base, flag))
+      bucket_insert_slow<W> (c0, c1, base, (u32) ((u64) fix[i].len & 0x3FFull), flag, k, BK, ctr);
+    else atomicAdd (&ctr->n_undefined, 1ull);
+  }
+}
+
 template <int W>
 __global__ __launch_bounds__ (TJ_SB_BLOCK, 6)
 void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_tiles, int k, int mprime,
@@ -1333,6 +1349,22 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
   sink.start ();
   scan_tiles<TJ_SB_BLOCK, TJ_SB_TILE, 2> (seq, n_bytes, n_tiles, k, mprime, T, raw, sink, ctr, fix, fix_cap, par, src);
   sink.finish ();
+  if (src.list) {
+    // Behind the fast kernel the fix-up of the listed runs is this kernel's last act instead of a launch of its own (which
+    // cost 4 us of stream time per scan for nothing: with no tile on the list, the usual case, every workgroup has left at
+    // the top and there is nothing to fix up).  The workgroup that finishes last does it: everybody's entries are released
+    // by a device-scope fence in front of the ticket and acquired by one behind it -- a path taken by streams with
+    // lower case, IUPAC codes or countable runs of 'N', where a fence's price does not matter.
+    __shared__ u32 s_last;
+    __threadfence ();
+    __syncthreads ();
+    if (threadIdx.x == 0) s_last = (atomicAdd (&ctr->lc[par].ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads ();
+    if (s_last) {
+      __threadfence ();
+      nrun_fixup_entries<W> (seq, n_bytes, k, mprime, BK, ctr, fix, fix_cap, par, threadIdx.x, blockDim.x);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1533,7 +1565,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       for (int t = 0; t < nt_all; t++) slow_list[t] = (u32) t;
       ctr->lc[par].n_slow = (u32) nt_all; ctr->lc[par].work = (u32) nt_all;
-      ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0;
+      ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; ctr->lc[par ^ 1].ticket = 0;
     }
     sink.finish ();
     return;
@@ -1543,7 +1575,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   if (wave == 0) {
     if (lane == 0) {
       T.grp[0] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP);
-      if (blockIdx.x == 0) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; }
+      if (blockIdx.x == 0) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; ctr->lc[par ^ 1].ticket = 0; }
     }
     if (lane < 4) { T.ncand[lane] = 0; T.bad[lane] = 0; T.code[FK_WIN / 16 + lane] = 0; T.st[FK_WIN / 32 + lane] = 0; T.lt[FK_WIN / 32 + lane] = 0; T.np[FK_WIN / 32 + lane] = 0; T.ncand2 = 0; }
   }
@@ -1938,14 +1970,7 @@ template <int W>
 __global__ void nrun_fixup_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, int k, int mprime,
                                         Buckets BK, DevCounters *ctr, const FixEntry *fix, u32 fix_cap, int par)
 {
-  u64 n_fix = ctr->lc[par].n_fix;
-  if (n_fix > fix_cap) n_fix = fix_cap;
-  for (u64 i = blockIdx.x * (u64) blockDim.x + threadIdx.x; i < n_fix; i += (u64) gridDim.x * blockDim.x) {
-    u64 c0, c1; u32 base, flag;
-    if (stale_context (seq, n_bytes, fix[i].pos, k, mprime, c0, c1, base, flag))
-      bucket_insert_slow<W> (c0, c1, base, (u32) ((u64) fix[i].len & 0x3FFull), flag, k, BK, ctr);
-    else atomicAdd (&ctr->n_undefined, 1ull);
-  }
+  nrun_fixup_entries<W> (seq, n_bytes, k, mprime, BK, ctr, fix, fix_cap, par, blockIdx.x * (u64) blockDim.x + threadIdx.x, (u64) gridDim.x * blockDim.x);
 }
 
 // host hopo_element array (40 B each) -> buckets
@@ -4077,8 +4102,10 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
       const TileSrc listed = {(const u32 *) c->slow.p, (long) FK_OWN}; \
       hipLaunchKernelGGL (scan_bins_kernel<WW>, dim3 (lgrid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, 0l, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, listed); \
     } \
-    else hipLaunchKernelGGL (scan_bins_kernel<WW>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, plain); \
-    hipLaunchKernelGGL (nrun_fixup_bins_kernel<WW>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par); \
+    else { \
+      hipLaunchKernelGGL (scan_bins_kernel<WW>, dim3 (grid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, n_tiles, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, plain); \
+      hipLaunchKernelGGL (nrun_fixup_bins_kernel<WW>, dim3 (64), dim3 (256), 0, c->stream, seq, (long) n_bytes, c->k, mprime, BK, c->d_ctr, (const FixEntry *) fix, (u32) TJ_FIX_CAP, par); \
+    } \
   } while (0)
   switch (c->W) {
     case 1: TJ_LAUNCH_SCAN (1); break;
