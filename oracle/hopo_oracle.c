@@ -9,9 +9,14 @@
  * The real reference cannot be built here as oracle/_ref: src/hopo_counter.c includes <biomcmc.h> and <wrapper_bwa.h>
  * from two submodules that are empty in /root/reference, and writing stand-in headers for them is ruled out, so it
  * is "unbuildable" and oracle/_ref does not exist.  What the reference does hold is checked in
- * tests/test_oracle_golden.py::test_reference_figure_and_readme_names: the three tracts of its figure
+ * tests/test_oracle_golden.py: (1) ::test_reference_figure_and_readme_names -- the three tracts of its figure
  * recipe/200322_001.png (read -> stored context, base, length; the T tract is the only reference-held statement of the
- * reverse-complement canonicalisation) and the names README.md:226-230 prints for them.  The other vectors under
+ * reverse-complement canonicalisation) and the names README.md:226-230 prints for them; (2)
+ * ::test_reference_second_figure_counts_and_length_histogram -- the context histogram of its second figure
+ * recipe/200322_002.png (README.md:234-240: CCG|GAT, A, reads per length 2: 10, 3: 20, 4: 6, 5: 2, typical length 3),
+ * which pins the dedupe count of orc_finalise (src/hopo_counter.c:356-365) and, in context_oracle.c, the order of a
+ * context's length histogram (src/context_histogram.c:278-286).  Still pinned by nothing reference-held: the order
+ * ACROSS contexts, the strand / singleton filter, the depth index and the coverage estimate.  The other vectors under
  * tests/golden/  were recorded by a survey-stage probe that compiled hopo_counter.c against stub
  * headers; they document what this file was written to and do not pin it.
  *

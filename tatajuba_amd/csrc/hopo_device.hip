@@ -978,6 +978,9 @@ struct StageSink
   u32 bound;                                            // upper bound of the records staged (workgroup-uniform)
   u32 cur_j, cur_chunk;                                 // owner thread (tid < TJ_P): the chunk its bucket is being written to
   STAMP_MEMBER
+#if defined(TJ_EXP_SINK) && TJ_EXP_SINK >= 4
+  u32 exp_cur = 0;
+#endif
 
   __device__ __forceinline__ void start ()
   {
@@ -1108,7 +1111,11 @@ struct StageSink
       if (FULL || (u32) r * BLOCK < n) {
         const u32 i = (u32) tid + (u32) r * BLOCK;
         if constexpr (!FULL) bb[r] = (i < n) ? bb[r] : (u32) (TJ_P + lane);
+#if defined(TJ_EXP_SINK) && TJ_EXP_SINK == 5            // experiment: no rank atomics (wrong results; cost of the LDS atomics)
+        rk[r] = 0; if (r == 0) L.hist[bb[r]] = 7u;
+#else
         rk[r] = atomicAdd (&L.hist[bb[r]], 1u);
+#endif
       }
     lds_barrier ();
     PSTAMP (10);
@@ -1125,7 +1132,11 @@ struct StageSink
       off = L.offs[tid];
       // reserve the bucket's run: the global atomic's round trip runs under the LDS permutation below (its result is
       // first looked at after that)
+#if defined(TJ_EXP_SINK) && TJ_EXP_SINK >= 4            // experiment builds only: a private cursor instead of the global atomic (results are wrong)
+      if (cnt) { p0 = cur_j == TJ_EMPTY ? 0u : exp_cur; exp_cur = (p0 + cnt) & 1023u; }
+#else
       if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
+#endif
     }
     else if (!FULL && wave == TJ_P / 64) L.offs[tid] = (u32) S + (u32) lane;   // (the spare entries: rank 0 lands on staging slot S + lane)
     lds_barrier ();

@@ -73,3 +73,24 @@ def scan_all_monomers(seq, k):
         if last is not None:
             out.append((last[0], 1, i - k, last[1], last[2], last[3]))
     return out
+
+
+def figure2_reads(fig2, both_strands=True):
+    """The reads behind the reference's second figure (recipe/200322_002.png, tests/golden/known_answers.json "figure2"):
+    for every drawn tract length n, `count` reads left + base^n + right -- half of them as the reverse complement when
+    `both_strands` (the figure does not say which strand a read came from; both store the same context)."""
+    comp = str.maketrans("ACGT", "TGCA")
+    reads = []
+    for n, cnt in sorted(fig2["reads_per_length"].items(), key=lambda t: int(t[0])):
+        fwd = fig2["left"] + fig2["base"] * int(n) + fig2["right"]
+        rev = fwd.translate(comp)[::-1]
+        for j in range(cnt):
+            reads.append(rev if (both_strands and j % 2) else fwd)
+    return reads
+
+
+def figure2_expected(fig2):
+    """(length, count) of the finalised elements in the reference's order (length descending inside the one context,
+    src/hopo_counter.c:28-38) and of the context's length histogram (highest count first, src/context_histogram.c:278-286)"""
+    bars = [(int(n), c) for n, c in fig2["reads_per_length"].items()]
+    return sorted(bars, key=lambda t: -t[0]), sorted(bars, key=lambda t: (-t[1], -t[0]))

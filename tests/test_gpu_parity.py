@@ -115,6 +115,58 @@ def test_reference_figure_through_the_bucket_scan(known_answers):
     assert len(got) == len(as_records(oracle_raw(s, 3, 2).elems()))
 
 
+@pytest.mark.parametrize("both_strands,remove_biased", [(True, 1), (True, 0), (False, 0)])
+def test_reference_second_figure_through_finalise_and_the_context_histogram(known_answers, tmp_path, both_strands, remove_biased):
+    """The reference's second figure (recipe/200322_002.png, README.md:234-240: context CCG|GAT, base A, reads per tract
+    length 2: 10, 3: 20, 4: 6, 5: 2, "a typical length would be 3") through the HIP path: bucket scan + finalise (count =
+    multiplicity per context and length, src/hopo_counter.c:356-365), tjamd_context_histograms (length histogram, highest
+    count first, src/context_histogram.c:278-286) and the drop-in new_genomic_context_list on a FASTQ file of those reads."""
+    from tatajuba_amd.capi import Options
+    from tests.pyref import figure2_expected, figure2_reads
+    f2 = known_answers["figure2"]
+    k, m = f2["k"], f2["m"]
+    reads = figure2_reads(f2, both_strands)
+    random.Random(2).shuffle(reads)
+    elems_exp, hist_exp = figure2_expected(f2)
+    s = np.frombuffer(("\n".join(reads) + "\n").encode(), np.uint8)
+    c = tj.Counter(k)
+    c.scan_host(s, m)
+    assert c.raw_count() == len(reads)
+    assert c.finalise(remove_biased, 5) == 0
+    kept = c.download_kept()
+    d = tj.decode_meta(kept["meta"])
+    assert [(int(d["length"][i]), int(d["count"][i])) for i in range(len(kept))] == elems_exp
+    assert (kept["ctx0"] == int(f2["ctx0"], 16)).all() and (kept["ctx1"] == int(f2["ctx1"], 16)).all() and (d["base"] == f2["base_code"]).all()
+    assert (d["canon_flag"] == (3 if both_strands else 1)).all()
+    gi, gf = c.download_idx()
+    assert c.n_idx == 1 and (gi[0], gf[0]) == (0, 4) and c.coverage == 38
+    got = c.context_histograms(1, 2)
+    (g,) = got["groups"]
+    assert (g["first"], g["n_elem"], g["n_context"], g["n_len"], g["integral"]) == (0, 4, 1, 4, 38)
+    assert list(zip(got["hist"]["length"][:4].tolist(), got["hist"]["freq"][:4].tolist())) == hist_exp
+    assert g["modal_len"] == f2["typical_length"] and g["modal_freq"] == 20
+    c.close()
+    # the same through the drop-in API: a file of those reads -> genomic_context_list with one context_histogram_t
+    fq = str(tmp_path / "figure2.fq")
+    with open(fq, "w") as fh:
+        fh.write("".join("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads)))
+    opt = Options.defaults(k, m, 5, bool(remove_biased))
+    opt.max_distance_per_flank, opt.levenshtein_distance = 1, 2
+    L = tj.lib()
+    h = tj.HopoCounter.new_or_append_from_file(None, fq, opt)
+    gl = L.new_genomic_context_list(h._p)
+    assert gl, "sample excluded"
+    gg = gl.contents
+    assert gg.n_hist == 1 and gg.coverage == 38
+    ch = gg.hist[0].contents
+    assert ch.name.decode() == "%s.%s.%s" % (f2["left"], f2["base"], f2["right"]) and ch.base == f2["base_code"]
+    assert (ch.n_context, ch.integral, ch.mode_context_count, ch.mode_context_length) == (1, 38, 20, f2["typical_length"])
+    hh = ch.h.contents
+    assert [(hh.i[t].idx, hh.i[t].freq) for t in range(hh.n)] == hist_exp
+    L.del_genomic_context_list(gl)
+    h.delete()
+
+
 def test_stale_context_and_undefined(known_answers):
     c0, c1 = known_answers["stale_context"]
     h = tj.HopoCounter.new(c0["k"])

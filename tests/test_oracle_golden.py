@@ -1,6 +1,6 @@
 """The CPU oracle against every known-answer vector there is for this path (tests/golden/known_answers.json).
-Reference-held: the three tracts of the reference's figure recipe/200322_001.png and the names README.md:226-230 gives
-them.  Not reference-held (they document what the oracle was written to): SURVEY.md 9.7's probe outputs.  Plus a
+Reference-held: the three tracts of the reference's figure recipe/200322_001.png, the names README.md:226-230 gives
+them, and the context histogram of its second figure recipe/200322_002.png (README.md:234-240).  Not reference-held (they document what the oracle was written to): SURVEY.md 9.7's probe outputs.  Plus a
 cross-check of the C state machine against an independent closed-form statement on random strings."""
 import os
 import random
@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import orc
-from tests.pyref import scan_all_monomers, scan_closed_form
+from tests.pyref import figure2_expected, figure2_reads, scan_all_monomers, scan_closed_form
 
 
 def records_of(o, k):
@@ -52,6 +52,38 @@ def test_reference_figure_and_readme_names(known_answers):
     readme = known_answers["readme"][0]["names_stored"]
     # the README's second name, ATC.A.CCG, is not what its own figure (and the code) stores: ATC.A.CGG -- see the note in the JSON
     assert names[0] == readme[0] and names[2] == readme[2] and names[1] == "ATC.A.CGG" and readme[1] == "ATC.A.CCG"
+
+
+@pytest.mark.parametrize("both_strands,remove_biased", [(True, 1), (True, 0), (False, 0)])
+def test_reference_second_figure_counts_and_length_histogram(known_answers, both_strands, remove_biased):
+    """recipe/200322_002.png (README.md:234-240): context CCG|GAT, base A, and per tract length the number of reads --
+    2: 10, 3: 20, 4: 6, 5: 2 -- "a typical length would be 3".  Reference-held statement of finalise step 2 (count =
+    multiplicity per context and length, src/hopo_counter.c:356-365) and of the length histogram of a context (highest
+    count first, src/context_histogram.c:278-286)."""
+    f2 = known_answers["figure2"]
+    k, m = f2["k"], f2["m"]
+    o = orc.Oracle(k)
+    for r in figure2_reads(f2, both_strands):
+        o.scan_seq(r, m)
+    assert o.c.n_elem == sum(f2["reads_per_length"].values())          # one tract per read, nothing else qualifies
+    o.finalise(remove_biased, 5)
+    assert o.c.status == 0
+    e = o.elems()
+    d = orc.decode_meta(e["meta"])
+    elems_exp, hist_exp = figure2_expected(f2)
+    assert [(int(d["length"][i]), int(d["count"][i])) for i in range(len(e))] == elems_exp
+    assert (e["ctx0"] == int(f2["ctx0"], 16)).all() and (e["ctx1"] == int(f2["ctx1"], 16)).all() and (d["base"] == f2["base_code"]).all()
+    assert (d["canon_flag"] == (3 if both_strands else 1)).all()
+    assert orc.name_of(e["ctx0"][0], e["ctx1"][0], d["base"][0], k) == "%s.%s.%s" % (f2["left"], f2["base"], f2["right"])
+    i0, i1 = o.idx()
+    assert o.c.n_idx == 1 and (i0[0], i1[0]) == (0, 4) and o.c.coverage == 38       # (derived, not drawn)
+    # the context's histogram of tract lengths
+    w = orc.genomic_context_list(e, k, 1, 2, m)
+    (g,) = w["groups"]
+    assert (g["first"], g["n_elem"], g["n_context"], g["n_len"], g["integral"]) == (0, 4, 1, 4, 38)
+    assert list(zip(w["hist_len"][:4].tolist(), w["hist_freq"][:4].tolist())) == hist_exp
+    assert g["modal_len"] == f2["typical_length"] and g["modal_freq"] == 20
+    assert g["mode_context_length"] == f2["typical_length"] and g["mode_context_count"] == 20
 
 
 def test_stale_context_quirk(known_answers):
