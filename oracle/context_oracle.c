@@ -172,7 +172,7 @@ orc_ef_cmp (const void *a, const void *b)
  * Returns the number of histograms. */
 long
 orc_genomic_context_list (const hopo_element *elem, long n, int kmer_size, int max_distance_per_flank, int levenshtein_distance,
-                          int min_tract_size, int *group_of, int *join_type, orc_group *g, int *hist_len, int *hist_freq, uint64_t *contexts)
+                          int min_tract_size, int genome_coverage, int *group_of, int *join_type, orc_group *g, int *hist_len, int *hist_freq, uint64_t *contexts)
 {
   long n_hist = 0, i, j;
   orc_ch *hist = (orc_ch *) malloc ((size_t) (n > 0 ? n : 1) * sizeof (orc_ch));
@@ -214,6 +214,7 @@ orc_genomic_context_list (const hopo_element *elem, long n, int kmer_size, int m
     g[i].first = ch->first; g[i].n_elem = ch->n_elem; g[i].n_context = ch->n_context; g[i].mode = ch->mode_elem;
     g[i].integral = ch->integral; g[i].indel = ch->indel; g[i].n_len = n_ef; g[i].modal_len = ef[0].idx; g[i].modal_freq = ef[0].freq;
     g[i].mode_context_id = ch->mode_context_id; g[i].mode_context_count = ch->mode_context_count; g[i].mode_context_length = ch->mode_context_length;
+    g[i].coverage = genome_coverage; g[i].n_tracts = (int) n_hist;     /* :302 (genome->coverage = hc->coverage, :240) */
     free (ef); free (ch->context); free (ch->name); free (ch->tmp_count); free (ch->tmp_length);
   }
   free (hist);

@@ -50,12 +50,13 @@ long orc_tract_ids (const uint64_t *rec3, long n, int *tract_id);
 typedef struct
 {
   int first, n_elem, n_context, mode, indel, n_len, modal_len, modal_freq, mode_context_id, mode_context_count, mode_context_length;
+  int coverage, n_tracts;     /* genome-wide figures copied onto every histogram (src/context_histogram.c:302) */
   long integral;
 } orc_group;
 char *orc_name_from_contexts (const uint64_t *context, int base, int kmer_size, int neg_strand);
 int orc_levenshtein (const char *s1, int n1, const char *s2, int n2, int cost_sub, int cost_indel);
 long orc_genomic_context_list (const hopo_element *elem, long n, int kmer_size, int max_distance_per_flank, int levenshtein_distance,
-                               int min_tract_size, int *group_of, int *join_type, orc_group *g, int *hist_len, int *hist_freq, uint64_t *contexts);
+                               int min_tract_size, int genome_coverage, int *group_of, int *join_type, orc_group *g, int *hist_len, int *hist_freq, uint64_t *contexts);
 long orc_merge_samples (const uint64_t *rec3, const long *counts_in, int n_samples, int *cat_sample, int *cat_index, uint64_t *keys3, int *counts);
 
 #endif

@@ -70,7 +70,7 @@ def lib():
         L.orc_name_from_contexts.restype = C.c_void_p; L.orc_name_from_contexts.argtypes = [U64P, C.c_int, C.c_int, C.c_int]
         L.orc_levenshtein.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]
         L.orc_genomic_context_list.restype = C.c_long
-        L.orc_genomic_context_list.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+        L.orc_genomic_context_list.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
         L.orc_merge_samples.restype = C.c_long
         L.orc_merge_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_parse_file_to_stream.restype = C.c_void_p
@@ -179,8 +179,8 @@ def tract_ids(rec3):
 
 ORC_GROUP_DTYPE = np.dtype([("first", "<i4"), ("n_elem", "<i4"), ("n_context", "<i4"), ("mode", "<i4"), ("indel", "<i4"), ("n_len", "<i4"),
                             ("modal_len", "<i4"), ("modal_freq", "<i4"), ("mode_context_id", "<i4"), ("mode_context_count", "<i4"),
-                            ("mode_context_length", "<i4"), ("_pad", "<i4"), ("integral", "<i8")])
-assert ORC_GROUP_DTYPE.itemsize == 56
+                            ("mode_context_length", "<i4"), ("coverage", "<i4"), ("n_tracts", "<i4"), ("_pad", "<i4"), ("integral", "<i8")])
+assert ORC_GROUP_DTYPE.itemsize == 64
 
 
 def levenshtein(a, b, cost_sub=1, cost_indel=1):
@@ -189,7 +189,7 @@ def levenshtein(a, b, cost_sub=1, cost_indel=1):
     return lib().orc_levenshtein(a, len(a), b, len(b), cost_sub, cost_indel)
 
 
-def genomic_context_list(elems, kmer_size, max_distance_per_flank, levenshtein_distance, min_tract_size):
+def genomic_context_list(elems, kmer_size, max_distance_per_flank, levenshtein_distance, min_tract_size, coverage=0):
     """oracle restatement of new_genomic_context_list (grouping with the indel retry + length histograms, see
     context_oracle.c).  Returns dict: group_of, join_type (per element), groups (ORC_GROUP_DTYPE), hist_len, hist_freq
     (per-element arrays: group g's histogram at [first, first + n_len)), contexts (uint64 [n, 2]: g's list at first ...)"""
@@ -199,7 +199,7 @@ def genomic_context_list(elems, kmer_size, max_distance_per_flank, levenshtein_d
     gof, jt, hl, hf = (np.zeros(m, np.int32) for _ in range(4))
     g = np.zeros(m, ORC_GROUP_DTYPE)
     ctx = np.zeros((m, 2), np.uint64)
-    ng = lib().orc_genomic_context_list(e.ctypes.data, n, kmer_size, max_distance_per_flank, levenshtein_distance, min_tract_size,
+    ng = lib().orc_genomic_context_list(e.ctypes.data, n, kmer_size, max_distance_per_flank, levenshtein_distance, min_tract_size, int(coverage),
                                         gof.ctypes.data, jt.ctypes.data, g.ctypes.data, hl.ctypes.data, hf.ctypes.data, ctx.ctypes.data)
     return {"group_of": gof[:n], "join_type": jt[:n], "groups": g[:ng], "hist_len": hl[:n], "hist_freq": hf[:n], "contexts": ctx[:n]}
 

@@ -51,84 +51,117 @@ indel_distance_between_context_histogram_and_hopo_context (context_histogram_t c
   return ctx_edit_distance (ch->name, len, name, len);
 }
 
-/* reference: src/context_histogram.c:25-48 */
+/* Summed mismatches of both flanks between one stored context pair and an element's, counted only as far as `budget`:
+ * the left flank is measured against the whole budget, the right flank against what the left one has left. */
+static int
+ctx_pair_mismatches (const uint64_t *pair, const hopo_element *he, int budget)
+{
+  int d = distance_between_single_context_kmer ((uint64_t *) &pair[0], (uint64_t *) &he->context[0], budget);
+  if (d < budget) d += distance_between_single_context_kmer ((uint64_t *) &pair[1], (uint64_t *) &he->context[1], budget - d);
+  return d;
+}
+
+/* How far an element is from a histogram (behaviour of src/context_histogram.c:25-48): CH_MAX_DIST for another base or a
+ * start further than `location_difference` from the histogram's; otherwise the contexts are tried in the order they were
+ * added -- the first one at or beyond 2 * max_distance ends the search with its distance, an identical one ends it with 0
+ * and its position in *idx_match -- and a search that runs to the end returns the largest distance it met. */
 int
 distance_between_context_histogram_and_hopo_context (context_histogram_t ch, hopo_element he, int max_distance, int location_difference, int *idx_match)
 {
-  int distance = 0, loc_diff, this_max = 0, i;
+  const int budget = 2 * max_distance;
+  const int apart = (he.read_offset > ch->location) ? he.read_offset - ch->location : ch->location - he.read_offset;
+  int c, worst = 0;
   *idx_match = -1;
-  if (ch->base != he.base) return CH_MAX_DIST;
-  loc_diff = he.read_offset - ch->location;
-  if (loc_diff < 0) loc_diff = -loc_diff;
-  if (loc_diff > location_difference) return CH_MAX_DIST;
-  for (i = 0; i < ch->n_context; i++) {
-    distance = distance_between_single_context_kmer (&(ch->context[2 * i]), &(he.context[0]), 2 * max_distance);
-    if (distance >= 2 * max_distance) return distance;
-    distance += distance_between_single_context_kmer (&(ch->context[2 * i + 1]), &(he.context[1]), 2 * max_distance - distance);
-    if (distance >= 2 * max_distance) return distance;
-    if (distance > this_max) this_max = distance;
-    if (distance == 0) { *idx_match = i; return 0; }
+  if (ch->base != he.base || apart > location_difference) return CH_MAX_DIST;
+  for (c = 0; c < ch->n_context; c++) {
+    const int d = ctx_pair_mismatches (ch->context + 2 * c, &he, budget);
+    if (d >= budget) return d;
+    if (d == 0) { *idx_match = c; return 0; }
+    if (d > worst) worst = d;
   }
-  return this_max;
+  return worst;
 }
 
-/* reference: new_context_histogram_from_hopo_elem, src/context_histogram.c:131-166 (tmp_count / tmp_length are not kept:
- * the length histogram comes from the device) */
-static context_histogram_t
-ctx_new (const hopo_element *he, char *name)
+static void *
+ctx_alloc (size_t bytes)
 {
-  context_histogram_t ch = (context_histogram_t) calloc (1, sizeof (struct context_histogram_struct));
-  if (!ch) ctx_fatal ("out of memory");
-  ch->context = (uint64_t *) malloc (2 * sizeof (uint64_t));
-  if (!ch->context) ctx_fatal ("out of memory");
-  ch->ref_counter = 1;
-  ch->n_context = 1;
-  ch->mode_context_id = 0;
-  ch->base = he->base;
-  ch->indel = 0;
-  ch->multi = he->multi;
+  void *p = calloc (1, bytes ? bytes : 1);
+  if (!p) ctx_fatal ("out of memory");
+  return p;
+}
+
+/* What a histogram takes from the element that represents it -- the first one, then every element with a count above all
+ * before it (src/context_histogram.c:141-155,192-203): where it is, how it mapped, its count and tract length. */
+static void
+ctx_take_representative (context_histogram_t ch, const hopo_element *he, int context_id)
+{
+  ch->mode_context_id = context_id;
   ch->mode_context_count = he->count;
   ch->mode_context_length = he->length;
-  ch->context[0] = he->context[0];
-  ch->context[1] = he->context[1];
   ch->location = he->read_offset;
-  ch->loc2d[0] = he->loc_ref_id; ch->loc2d[1] = he->loc_pos; ch->loc2d[2] = he->loc_last;
+  ch->loc2d[0] = he->loc_ref_id;
+  ch->loc2d[1] = he->loc_pos;
+  ch->loc2d[2] = he->loc_last;
   ch->mismatches = he->mismatches;
   ch->neg_strand = he->neg_strand;
-  ch->integral = he->count;
-  ch->name = name;
-  ch->h = NULL;
-  ch->index = -1;
-  ch->tmp_count = ch->tmp_length = NULL;
-  ch->tract_id = -1;
-  return ch;
 }
 
-/* reference: context_histogram_add_hopo_elem, src/context_histogram.c:181-222 */
-static void
-ctx_add (context_histogram_t ch, const hopo_element *he, char *name, int idx_match)
+/* One histogram from the elements [first, first + n_elem) that the device put together (join_type: how each one joined).
+ * Same outcome as the reference's element-by-element bookkeeping (src/context_histogram.c:131-166,181-222), built in one
+ * go: the device has already said how many distinct contexts there are and which element is the modal one, so the
+ * context list is allocated once and only the modal element's name is ever made. */
+static context_histogram_t
+ctx_build (const hopo_element *elem, const int *join_type, const tjamd_context_group *grp, const tjamd_length_freq *lf, int kmer_size)
 {
-  if (idx_match < 0) {
-    ch->context = (uint64_t *) realloc (ch->context, 2 * (size_t) (ch->n_context + 1) * sizeof (uint64_t));
-    if (!ch->context) ctx_fatal ("out of memory");
-    idx_match = ch->n_context++;
-    ch->context[2 * idx_match] = he->context[0];
-    ch->context[2 * idx_match + 1] = he->context[1];
+  context_histogram_t ch = (context_histogram_t) ctx_alloc (sizeof (struct context_histogram_struct));
+  const hopo_element *he = elem + grp->first;
+  int e, t, n_ctx = 0, modal_context = 0, best = he->count;
+
+  ch->context = (uint64_t *) ctx_alloc (2 * (size_t) grp->n_context * sizeof (uint64_t));
+  ch->ref_counter = 1;
+  ch->base = he->base;
+  ch->multi = he->multi;
+  ch->index = -1;
+  ch->tract_id = -1;
+  for (e = 0; e < grp->n_elem; e++, he++) {
+    int at = -1;
+    /* an element within the flank distance that met its own context in the list is counted there (the search of :36-46
+     * stops at the first identical context); the opener, and an element taken in by the retry, always add theirs */
+    if (e > 0 && join_type[grp->first + e] == 1)
+      for (t = 0; t < n_ctx && at < 0; t++)
+        if (ch->context[2 * t] == he->context[0] && ch->context[2 * t + 1] == he->context[1]) at = t;
+    if (at < 0) {
+      if (n_ctx >= grp->n_context) ctx_fatal ("new_genomic_context_list: host bookkeeping and device summary disagree (contexts)");
+      at = n_ctx++;
+      ch->context[2 * at] = he->context[0];
+      ch->context[2 * at + 1] = he->context[1];
+    }
+    if (e == 0 || he->count > best) { best = he->count; modal_context = at; ctx_take_representative (ch, he, at); }
+    if (e > 0) {
+      if (join_type[grp->first + e] == 2) ch->indel = 1;  /* :260 (a bool in a 2-bit signed field) */
+      if ((ch->multi ^ he->multi) == 1) ch->multi = 2;    /* :219 */
+    }
+    ch->integral += he->count;
   }
-  if (ch->mode_context_count < he->count) {
-    ch->mode_context_count = he->count;
-    ch->mode_context_length = he->length;
-    ch->mode_context_id = idx_match;
-    ch->location = he->read_offset;
-    ch->loc2d[0] = he->loc_ref_id; ch->loc2d[1] = he->loc_pos; ch->loc2d[2] = he->loc_last;
-    ch->mismatches = he->mismatches;
-    ch->neg_strand = he->neg_strand;
-    free (ch->name);
-    ch->name = name;
+  if (n_ctx != grp->n_context || ch->integral != (int) grp->integral || ch->mode_context_id != modal_context)
+    ctx_fatal ("new_genomic_context_list: host bookkeeping and device summary disagree");
+  ch->n_context = n_ctx;
+  he = elem + grp->mode;                                  /* the device's modal element: first one with the highest count */
+  if (he->count != ch->mode_context_count || he->length != ch->mode_context_length)
+    ctx_fatal ("new_genomic_context_list: host and device disagree on the modal element");
+  ch->name = generate_name_from_flanking_contexts ((uint64_t *) he->context, (int8_t) he->base, kmer_size, he->neg_strand);
+  /* tract lengths weighted by count, highest count first (:282 new_empfreq_from_int_weighted): from the device */
+  ch->h = (empfreq) ctx_alloc (sizeof (struct empfreq_struct));
+  ch->h->n = grp->n_len;
+  ch->h->i = (empfreq_element *) ctx_alloc ((size_t) grp->n_len * sizeof (empfreq_element));
+  ch->h->min = ch->h->max = lf[0].length;
+  for (t = 0; t < grp->n_len; t++) {
+    ch->h->i[t].idx = lf[t].length;
+    ch->h->i[t].freq = lf[t].freq;
+    if (lf[t].length < ch->h->min) ch->h->min = lf[t].length;
+    if (lf[t].length > ch->h->max) ch->h->max = lf[t].length;
   }
-  else free (name);
-  if ((ch->multi ^ he->multi) == 1) ch->multi = 2;
-  ch->integral += he->count;
+  return ch;
 }
 
 void
@@ -155,8 +188,9 @@ del_genomic_context_list (genomic_context_list_t genome)
   free (genome);
 }
 
-/* reference: src/context_histogram.c:224-272 + step 1 of finalise_genomic_context_hist (:278-286).  Steps 2-4 of the latter
- * (GFF3 features, location order, same-location merge) need the aligner's locations and are not done: ref_start = 0. */
+/* reference: src/context_histogram.c:224-272 + steps 1 and 5 of finalise_genomic_context_hist (:278-286, :302).  Steps
+ * 2-4 of the latter (GFF3 features, location order, same-location merge) need the aligner's locations and are not done:
+ * ref_start = 0. */
 genomic_context_list_t
 new_genomic_context_list (hopo_counter hc)
 {
@@ -165,66 +199,42 @@ new_genomic_context_list (hopo_counter hc)
   tjamd_context_group *groups;
   tjamd_length_freq *lf;
   int *join_type;
-  long n, ng, g, i;
+  long n, ng, g;
 
   finalise_hopo_counter (hc);                           /* :231 */
-  if (hc->ref_start == hc->n_elem) {                    /* :232-235 */
-    fprintf (stderr, "tatajuba_amd warning: Sample %s doesn't contain any HT mapped to reference: it will be excluded from analysis\n", hc->name);
+  if (hc->ref_start != 0 && hc->ref_start != hc->n_elem) {
+    /* Only a host program's own find_reference_location_and_sort_hopo_counter (the weak hook finalise_hopo_counter calls
+     * when it is linked) sets ref_start: it has re-sorted hc->elem by location, and the grouping decisions held on the
+     * device are in the finalised order, not that one.  Applying them would give wrong histograms: stop. */
+    ctx_fatal ("new_genomic_context_list: hc->elem was re-ordered after finalise_hopo_counter (ref_start != 0: an aligner hook is linked); "
+               "location-ordered grouping is outside this library -- see INTEGRATION.md, \"with an aligner\"");
+  }
+  if (hc->ref_start == hc->n_elem) {                    /* :232-235: with no aligner linked this is "nothing left after the filters" */
+    fprintf (stderr, "tatajuba_amd warning: Sample %s holds no homopolymeric tract after the strand / depth filters: it will be excluded from analysis\n",
+             hc->name ? hc->name : "(unnamed)");
     return NULL;
   }
   n = hc->n_elem;
   dev = tj_counter_device (hc);
   if (!dev || tjamd_kept_count (dev) != n) ctx_fatal ("new_genomic_context_list: the counter's device histogram is gone (the counter was reused after finalise_hopo_counter)");
-  groups = (tjamd_context_group *) malloc ((size_t) n * sizeof (tjamd_context_group));
-  lf = (tjamd_length_freq *) malloc ((size_t) n * sizeof (tjamd_length_freq));
-  join_type = (int *) malloc ((size_t) n * sizeof (int));
-  genome = (genomic_context_list_t) malloc (sizeof (struct genomic_context_list_struct));
-  if (!groups || !lf || !join_type || !genome) ctx_fatal ("out of memory");
+  groups = (tjamd_context_group *) ctx_alloc ((size_t) n * sizeof (tjamd_context_group));
+  lf = (tjamd_length_freq *) ctx_alloc ((size_t) n * sizeof (tjamd_length_freq));
+  join_type = (int *) ctx_alloc ((size_t) n * sizeof (int));
   ng = tjamd_context_histograms (dev, hc->opt.max_distance_per_flank, hc->opt.levenshtein_distance, NULL, join_type, groups, lf, n);
   if (ng < 0) ctx_fatal (tjamd_last_error ());
 
-  genome->hist = (context_histogram_t *) malloc ((size_t) ng * sizeof (context_histogram_t));
-  if (!genome->hist) ctx_fatal ("out of memory");
+  genome = (genomic_context_list_t) ctx_alloc (sizeof (struct genomic_context_list_struct));
+  genome->hist = (context_histogram_t *) ctx_alloc ((size_t) ng * sizeof (context_histogram_t));
   genome->n_hist = (int) ng;
   genome->opt = hc->opt;
   genome->coverage = hc->coverage;
-  genome->name = hc->name;                              /* :241-242 */
+  genome->name = hc->name;                              /* :241-242: the list takes the counter's name */
   hc->name = NULL;
   genome->ref_start = 0;
-
   for (g = 0; g < ng; g++) {
-    const long first = groups[g].first;
-    context_histogram_t ch = NULL;
-    int t;
-    for (i = first; i < first + groups[g].n_elem; i++) {
-      const hopo_element *he = &hc->elem[i];
-      char *name = generate_name_from_flanking_contexts ((uint64_t *) he->context, (int8_t) he->base, genome->opt.kmer_size, he->neg_strand);
-      if (i == first) { ch = ctx_new (he, name); continue; }
-      {
-        /* the device says how the element joined; which context of the list it met (idx_match) follows: within the flank
-         * distance the loop of :36-46 stops at the first identical context, the retry never has a match */
-        int idx_match = -1;
-        if (join_type[i] == 1)
-          for (t = 0; t < ch->n_context && idx_match < 0; t++)
-            if (ch->context[2 * t] == he->context[0] && ch->context[2 * t + 1] == he->context[1]) idx_match = t;
-        ctx_add (ch, he, name, idx_match);
-        if (join_type[i] == 2) ch->indel = 1;           /* :260 (a bool stored in a 2-bit signed field) */
-      }
-    }
-    /* :282 new_empfreq_from_int_weighted (lengths, n, counts): from the device */
-    ch->h = (empfreq) malloc (sizeof (struct empfreq_struct));
-    if (!ch->h) ctx_fatal ("out of memory");
-    ch->h->n = groups[g].n_len;
-    ch->h->i = (empfreq_element *) malloc ((size_t) ch->h->n * sizeof (empfreq_element));
-    if (!ch->h->i) ctx_fatal ("out of memory");
-    ch->h->min = ch->h->max = lf[first].length;
-    for (t = 0; t < ch->h->n; t++) {
-      ch->h->i[t].idx = lf[first + t].length; ch->h->i[t].freq = lf[first + t].freq;
-      if (ch->h->i[t].idx < ch->h->min) ch->h->min = ch->h->i[t].idx;
-      if (ch->h->i[t].idx > ch->h->max) ch->h->max = ch->h->i[t].idx;
-    }
-    if (ch->n_context != groups[g].n_context || ch->integral != (int) groups[g].integral)
-      ctx_fatal ("new_genomic_context_list: host bookkeeping and device summary disagree");
+    context_histogram_t ch = ctx_build (hc->elem, join_type, &groups[g], lf + groups[g].first, genome->opt.kmer_size);
+    ch->coverage = genome->coverage;                    /* :302: genome-wide figures on every histogram */
+    ch->n_tracts = genome->n_hist;
     genome->hist[g] = ch;
   }
   free (groups); free (lf); free (join_type);

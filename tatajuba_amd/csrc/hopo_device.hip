@@ -1133,7 +1133,7 @@ struct StageSink
       // reserve the bucket's run: the global atomic's round trip runs under the LDS permutation below (its result is
       // first looked at after that)
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK >= 4            // experiment builds only: a private cursor instead of the global atomic (results are wrong)
-      if (cnt) { p0 = cur_j == TJ_EMPTY ? 0u : exp_cur; exp_cur = (p0 + cnt) & 1023u; }
+      if (cnt) { p0 = exp_cur; exp_cur = (p0 + cnt) & 255u; }
 #else
       if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
 #endif
@@ -1162,7 +1162,12 @@ struct StageSink
       // launch, 1 % slower; the exec regions below are cheaper than they look)
       u64 a1 = 0, a2 = 0;
       u32 thr = 0;
+#if defined(TJ_EXP_SINK) && TJ_EXP_SINK >= 4            // (experiment: every workgroup writes to a 4 KB region of its own per bucket)
+      if (cnt && cnt <= 256u) { a1 = (u64) (size_t) B.pool + (((((u64) tid * 512u + (blockIdx.x & 511u)) * 512u) + p0) << 3) - 8ull * off; thr = off + cnt; }
+      if (0) {
+#else
       if (cnt) {
+#endif
         const u32 ch = (u32) TJ_CH0 << B.ch_shift;
         bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
         const u32 j0 = chunk_of_pos (B, p0), j1 = chunk_of_pos (B, p0 + cnt - 1);
@@ -1804,6 +1809,9 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     // (`bound` has counted candidates, of which one in eight is not recorded -- with the true count the buffer is
     // partitioned when it is full)
     sink.bound = (u32) __builtin_amdgcn_readfirstlane ((int) staged_v);
+#if defined(FK_EXP_LINEAR)
+    sink.bound = 0;
+#endif
     u32 ncand_now = ncand_all;
     if (ncand_all >= 0x40000000u) {
       // Second chance for a tile with a byte outside the five: if all such bytes are 'N' (the no-call of every sequencer),
@@ -1931,7 +1939,11 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         // wave) and the record is worked out while that is on its way
         const u64 okm = __builtin_amdgcn_ballot_w64 (ok);
         u32 araw;
+#if defined(FK_EXP_SCATTER)
+        lds_add_issue (sink.count_addr (), 0u, araw);
+#else
         lds_add_issue (sink.count_addr (), (u32) __builtin_popcountll (okm), araw);
+#endif
 #endif
         const u32 sh = u + u;
         const u32 clo = __builtin_amdgcn_alignbit (w1, w0, sh), chi = __builtin_amdgcn_alignbit (w2, w1, sh);
@@ -1958,8 +1970,30 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #if defined(FK_EXP_STOP) && FK_EXP_STOP == 3
         if (ok) asm volatile ("" :: "v"(lo), "v"(hi), "v"(at));
 #else
+#if defined(FK_EXP_LINEAR)                              // experiment: no staging, no partition: records to a linear log of the workgroup's own
+        {
+          const u32 at = lds_collect (araw) + (u32) __builtin_amdgcn_mbcnt_hi ((u32) (okm >> 32), __builtin_amdgcn_mbcnt_lo ((u32) okm, 0u));
+          typedef __attribute__((address_space(1))) u64 *gwords_t;
+          gwords_t q = (gwords_t) ((u64) (size_t) BK.pool + (((u64) blockIdx.x * 200000u + (at % 200000u)) << 3));
+          if (ok) *q = ((u64) hi << 32) | lo;
+        }
+#elif defined(FK_EXP_SCATTER)                           // experiment: no staging, every record straight to a private place of its bucket (wrong results)
+        (void) lds_collect (araw);
+        {
+          u32 h = __builtin_amdgcn_udot4 (lo, vh0, 0u, false);
+          h = __builtin_amdgcn_udot4 (hi & vm27, vh1, h, false);
+          const u32 bin = ok ? ((h ^ (h >> 8)) & 255u) : 256u + (u32) lane;
+          const u32 r = atomicAdd (&SL.hist[bin], 1u);
+          const uint4 e = reinterpret_cast<const uint4 *> (SL.gbase)[bin & 255u];
+          asm volatile ("" :: "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));
+          typedef __attribute__((address_space(1))) u64 *gwords_t;
+          gwords_t q = (gwords_t) ((u64) (size_t) BK.pool + ((((u64) (bin & 255u) * 512u + (blockIdx.x & 511u)) * 512u + (r & 511u)) << 3));
+          if (ok) *q = ((u64) hi << 32) | lo;
+        }
+#else
         const u32 at = lds_collect (araw) + (u32) __builtin_amdgcn_mbcnt_hi ((u32) (okm >> 32), __builtin_amdgcn_mbcnt_lo ((u32) okm, 0u));
         sink.store1v (ok ? at : (u32) sink.S + (u32) lane, lo, hi, vh0, vh1, vm27);   // (no record: a spare slot takes the write)
+#endif
 #endif
         STAMP (7);
       }

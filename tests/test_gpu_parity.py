@@ -161,6 +161,7 @@ def test_reference_second_figure_through_finalise_and_the_context_histogram(know
     ch = gg.hist[0].contents
     assert ch.name.decode() == "%s.%s.%s" % (f2["left"], f2["base"], f2["right"]) and ch.base == f2["base_code"]
     assert (ch.n_context, ch.integral, ch.mode_context_count, ch.mode_context_length) == (1, 38, 20, f2["typical_length"])
+    assert (ch.coverage, ch.n_tracts) == (38, 1)
     hh = ch.h.contents
     assert [(hh.i[t].idx, hh.i[t].freq) for t in range(hh.n)] == hist_exp
     L.del_genomic_context_list(gl)
@@ -1060,7 +1061,7 @@ def test_new_genomic_context_list_drop_in(tmp_path, k, maxd, lev):
     o.finalise(0, 2)
     assert o.c.status == 0 and h.c.n_elem == o.c.n_elem and g.coverage == o.c.coverage
     e = o.elems()
-    w = orc.genomic_context_list(e, k, maxd, lev, m)
+    w = orc.genomic_context_list(e, k, maxd, lev, m, o.c.coverage)
     wg = w["groups"]
     assert g.n_hist == len(wg) and g.ref_start == 0 and g.name == os.fsencode(fq)
     meta = orc.decode_meta(e["meta"])
@@ -1071,6 +1072,7 @@ def test_new_genomic_context_list_drop_in(tmp_path, k, maxd, lev):
         assert (ch.n_context, ch.integral, ch.mode_context_count, ch.mode_context_length, ch.mode_context_id) == \
             (x["n_context"], x["integral"], x["mode_context_count"], x["mode_context_length"], x["mode_context_id"]), i
         assert (ch.indel != 0) == bool(x["indel"]) and ch.base == meta["base"][f] and ch.location == -1 and ch.tract_id == -1
+        assert (ch.coverage, ch.n_tracts) == (x["coverage"], x["n_tracts"]) == (o.c.coverage, len(wg))   # src/context_histogram.c:302
         n_indel += int(x["indel"])
         assert [ch.context[t] for t in range(2 * ch.n_context)] == w["contexts"][f:f + ch.n_context].reshape(-1).tolist(), i
         mo = int(x["mode"])
@@ -1082,6 +1084,24 @@ def test_new_genomic_context_list_drop_in(tmp_path, k, maxd, lev):
     assert n_indel > 0 and g.n_hist < len(e)                 # the retry and the grouping both did something
     L.del_genomic_context_list(gl)
     h.delete()
+
+
+def test_context_list_refuses_elements_reordered_by_an_aligner_hook(tmp_path, golden_dir):
+    """A host program that links find_reference_location_and_sort_hopo_counter (the weak hook at the place of the
+    reference's BWA step, src/hopo_counter.c:416) gets hc->elem re-ordered and ref_start > 0: new_genomic_context_list must
+    stop with a message, not apply the device's grouping to the re-ordered array (tests/c/hook_guard.c).  With a hook that
+    leaves the array alone the list is built."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "tatajuba_amd")
+    exe = str(tmp_path / "hook_guard")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "hook_guard.c"),
+                           "-L", libdir, "-ltatajuba_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    fq = os.path.join(golden_dir, "err1750956.fastq.gz")
+    r = subprocess.run([exe, fq, "10", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "re-ordered after finalise_hopo_counter" in r.stderr and "histograms" not in r.stdout
+    r = subprocess.run([exe, fq, "10", "3", "keep"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "hook calls 1, histograms " in r.stdout and "histograms -1" not in r.stdout
 
 
 def test_tract_ids_and_in_process_gather():
