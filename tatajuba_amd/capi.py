@@ -90,7 +90,7 @@ EXPORTS = [
     "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_finalise_begin", "tjamd_finalise_end", "tjamd_kept_count",
     "tjamd_n_idx", "tjamd_coverage", "tjamd_download_kept", "tjamd_download_idx", "tjamd_kept_device_ptr",
     "tjamd_merge_samples", "tjamd_gather_histograms", "tjamd_peer_access_report", "tjamd_comm_unique_id", "tjamd_comm_create", "tjamd_comm_destroy",
-    "tjamd_comm_set_stream", "tjamd_comm_rank", "tjamd_comm_world", "tjamd_comm_collectives", "tjamd_allgather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_context_histograms", "tjamd_scan_windows", "tjamd_thread_cleanup", "tjamd_last_scan_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches", "tjamd_plan_mismatches",
+    "tjamd_comm_set_stream", "tjamd_comm_rank", "tjamd_comm_world", "tjamd_comm_collectives", "tjamd_allgather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_context_histograms", "tjamd_scan_windows", "tjamd_thread_cleanup", "tjamd_last_scan_ms", "tjamd_last_partition_ms", "tjamd_last_finalise_ms", "tjamd_last_scan_launches", "tjamd_plan_mismatches",
     "tjamd_synth_stream", "tjamd_read_file_stream",
     # include/tatajuba_context.h
     "new_genomic_context_list", "del_genomic_context_list", "del_context_histogram",
@@ -213,6 +213,7 @@ def lib():
     L.hopo_counter_histogram_integral.argtypes = [P, C.c_int]
     L.tjamd_last_scan_ms.restype = C.c_double; L.tjamd_last_scan_ms.argtypes = [C.c_void_p]
     L.tjamd_last_finalise_ms.restype = C.c_double; L.tjamd_last_finalise_ms.argtypes = [C.c_void_p]
+    L.tjamd_last_partition_ms.restype = C.c_double; L.tjamd_last_partition_ms.argtypes = [C.c_void_p]
     L.tjamd_last_scan_launches.restype = C.c_long; L.tjamd_last_scan_launches.argtypes = [C.c_void_p]
     L.tjamd_synth_stream.restype = C.c_long
     L.tjamd_synth_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_long, C.c_long, C.c_int, C.c_int,
@@ -483,6 +484,9 @@ class Counter:
 
     def last_scan_ms(self):
         return lib().tjamd_last_scan_ms(self._h)
+
+    def last_partition_ms(self):
+        return lib().tjamd_last_partition_ms(self._h)
 
     def last_finalise_ms(self):
         return lib().tjamd_last_finalise_ms(self._h)

@@ -194,10 +194,22 @@ struct Stamper
 #define ASTAMP_DECL unsigned long long a_last = __builtin_amdgcn_s_memtime (), a_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define ASTAMP(i) { unsigned long long t_ = __builtin_amdgcn_s_memtime (); a_acc[i] += t_ - a_last; a_last = t_; }
 #define ASTAMP_FLUSH if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd (&tj_stamp_acc[16 + i_], a_acc[i_])
+#if TJ_STAMPS == 2                                      // (the partition kernel's stamps alone)
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#define PLSTAMP_DECL Stamper stamper; stamper.begin (); sink.stp = &stamper
+#define PLSTAMP(i) stamper.mark (i)
+#define PLSTAMP_FLUSH stamper.flush ()
+#else
 #define STAMP_DECL Stamper stamper; stamper.begin (); sink.stp = &stamper
 #define STAMP(i) stamper.mark (i)
-#define PSTAMP(i) stp->mark (i)
 #define STAMP_FLUSH stamper.flush ()
+#define PLSTAMP_DECL
+#define PLSTAMP(i)
+#define PLSTAMP_FLUSH
+#endif
+#define PSTAMP(i) stp->mark (i)
 #define STAMP_MEMBER Stamper *stp;
 extern "C" int tjamd_debug_stamps (unsigned long long *out, int reset)
 {
@@ -215,6 +227,9 @@ extern "C" int tjamd_debug_stamps (unsigned long long *out, int reset)
 #define PSTAMP(i)
 #define STAMP_FLUSH
 #define STAMP_MEMBER
+#define PLSTAMP_DECL
+#define PLSTAMP(i)
+#define PLSTAMP_FLUSH
 #endif
 
 // inclusive prefix sum over the 64 lanes of a wavefront with DPP adds (row shifts inside 16-lane rows, then the two
@@ -854,6 +869,12 @@ __device__ __forceinline__ u32 bucket_of_rec1 (u32 lo, u32 hi)
 // TJ_STAGE_WORDS: 64-bit words of one-word records a workgroup stages in LDS between partition passes (twice that in the fast kernel)
 #define TJ_CH0      1536                // chunk size unit in records; chunks are TJ_CH0 << ch_shift with ch_shift >= 2
 #define TJ_EMPTY    0xFFFFFFFFu
+// The bucket cursors take every reservation of every workgroup (millions of atomic adds per launch): each lives on a
+// 256-byte line of its own, so that they spread over the memory channels instead of queueing up at the one or two that
+// a packed 1 KB array maps to.  cursors[TJ_P * TJ_CSTRIDE] = the next free chunk.
+#ifndef TJ_CSTRIDE
+#define TJ_CSTRIDE  64
+#endif
 
 // Bucket storage.  A bucket is a sequence of records numbered by its cursor; a workgroup reserves a run of positions
 // with one atomic add and record `pos` lives in the bucket's (pos / CH)-th chunk (runs are shorter than a chunk, so a
@@ -865,7 +886,7 @@ struct Buckets
 {
   u64 *pool;          // pool_chunks * CH * W words
   u32 *table;         // [TJ_P][maxj] chunk ids, TJ_EMPTY = not claimed yet
-  u32 *cursors;       // [TJ_P] records reserved per bucket
+  u32 *cursors;       // records reserved per bucket b at [b * TJ_CSTRIDE]
   u32 *pool_next;     // next free chunk
   u32 pool_chunks, maxj, ch_shift;      // CH = TJ_CH0 << ch_shift
 };
@@ -885,6 +906,18 @@ __device__ __forceinline__ void bucket_claim_ahead (const Buckets &B, u32 b, u32
   const u32 mine = atomicAdd (B.pool_next, 1u);
   if (mine >= B.pool_chunks) ctr->overflow = 1u;
   __hip_atomic_store (B.table + (u64) b * B.maxj + j + 1, mine < B.pool_chunks ? mine : TJ_NOCHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the same for a reservation of any length: every chunk whose first record lies in [p0, p0 + n) has its successor claimed
+__device__ __forceinline__ void bucket_claim_ahead_range (const Buckets &B, u32 b, u32 p0, u32 n, DevCounters *ctr)
+{
+  const u32 ch = (u32) TJ_CH0 << B.ch_shift;
+  for (u32 j = (p0 + ch - 1u) / ch; (u64) j * ch < (u64) p0 + n; j++) {
+    if (j + 1 >= B.maxj) { ctr->overflow = 1u; return; }
+    const u32 mine = atomicAdd (B.pool_next, 1u);
+    if (mine >= B.pool_chunks) ctr->overflow = 1u;
+    __hip_atomic_store (B.table + (u64) b * B.maxj + j + 1, mine < B.pool_chunks ? mine : TJ_NOCHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // chunk id of the j-th chunk of bucket b (TJ_NOCHUNK if it has none).  wait = the entry may still be on its way from
@@ -919,7 +952,7 @@ __device__ __forceinline__ void bucket_insert_slow (u64 c0, u64 c1, u32 base, u3
   u64 w[W];
   pack_raw<W> (c0, c1, base, len10, flag, k, w);
   const u32 b = (W == 1) ? bucket_of_rec1 ((u32) w[0], (u32) (w[0] >> 32)) : bucket_of_key (c0, c1, base, len10);
-  const u32 pos = atomicAdd (&B.cursors[b], 1u);
+  const u32 pos = atomicAdd (&B.cursors[b * TJ_CSTRIDE], 1u);
   bucket_claim_ahead (B, b, pos, 1u, ctr);
   const u64 at = bucket_slot (B, b, pos, true, ctr);
   if (at != ~0ull) { u64 *q = B.pool + at * W; for (int j = 0; j < W; j++) q[j] = w[j]; }
@@ -932,7 +965,7 @@ __device__ __forceinline__ void bucket_insert_slow (u64 c0, u64 c1, u32 base, u3
 // write every run out contiguously.  All the fixed costs of partitioning (barriers, reservations, chunk look-ups) are
 // paid once per ~4096 records instead of once per tile.
 
-template <int W, bool BIG = false>
+template <int W, int BIG = 0>
 struct StageLds
 {
   // a staged record is WS words (the 4th word of a W = 4 record is padding and only exists in HBM); the two-word and
@@ -943,7 +976,8 @@ struct StageLds
   // (4096 one-word records -- twice the records per pass, runs twice as long -- or 2048 two-word ones: the fast kernel's
   // LDS budget is the same for every k), and every array has 64 spare entries so that partition_big can do without
   // per-record branches
-  static constexpr int WORDS = BIG ? TJ_STAGE_WORDS * 2 : (W == 1) ? TJ_STAGE_WORDS : 2688;
+  // BIG = 2: partition_log_kernel's (two workgroups per CU and nothing else in LDS): 8192 one-word records per pass
+  static constexpr int WORDS = BIG == 2 ? 8192 : BIG ? TJ_STAGE_WORDS * 2 : (W == 1) ? TJ_STAGE_WORDS : 2688;
   static constexpr int S = WORDS / WS;                   // records
   static constexpr int SPARE = BIG ? 64 : 0;
   u64 rec[WORDS + SPARE * WS];                          // (BIG: slots S + lane take the writes of lanes without a record)
@@ -951,7 +985,7 @@ struct StageLds
   u64 gbase2[TJ_P];                                     // pool index of the part of the run that lies in the next chunk
   alignas (16) u32 hist[TJ_P + SPARE];                  // (BIG: entries TJ_P + lane are for the lanes without a record)
   alignas (16) u32 offs[TJ_P + SPARE];                               // start of the bucket's run in the sorted staging buffer
-  u32 split[TJ_P];                                      // records of the run before the chunk boundary (BIG: first sorted slot past it)
+  u32 split[BIG == 2 ? 1 : TJ_P];                       // records of the run before the chunk boundary (BIG: not used, the threshold travels in gbase's entry)
   u32 wsum[TJ_P / 64];
   u32 n;
   unsigned char bin[S + SPARE];
@@ -960,7 +994,7 @@ struct StageLds
 typedef StageLds<1, true> StageLdsFast1;
 static_assert (offsetof (StageLdsFast1, gbase2) == offsetof (StageLdsFast1, gbase) + sizeof (u64) * TJ_P, "gbase and gbase2 back to back");
 
-template <int W, int BLOCK, bool BIG = false>
+template <int W, int BLOCK, int BIG = 0>
 struct StageSink
 {
   static constexpr bool K32 = (W == 1);                 // k <= 12: the scan may use 32-bit k-mer arithmetic
@@ -977,6 +1011,7 @@ struct StageSink
   Buckets B; DevCounters *ctr; int k;
   u32 bound;                                            // upper bound of the records staged (workgroup-uniform)
   u32 cur_j, cur_chunk;                                 // owner thread (tid < TJ_P): the chunk its bucket is being written to
+  u32 blk_p0 = 0;                                       // owner thread, partition_pass<.., EXT>: next position of the run reserved for the bucket
   STAMP_MEMBER
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK >= 4
   u32 exp_cur = 0;
@@ -1081,8 +1116,12 @@ struct StageSink
   }
 
   // FULL: the pass takes exactly the first PS staged records (all RR rounds are full); otherwise all n of them
-  template <bool FULL>
-  __device__ __forceinline__ u32 partition_pass (const u32 n)
+  // gsrc: the n records come from global memory (partition_log_kernel: one-word records, nothing staged) instead of the
+  // staging buffer
+  // EXT: the bucket's run was reserved by the caller for several passes at once (owner thread: blk_p0 = its next free
+  // position; partition_log_kernel reserves once per log block)
+  template <bool FULL, bool EXT = false>
+  __device__ __forceinline__ u32 partition_pass (const u32 n, const u64 *__restrict__ gsrc = nullptr)
   {
     static_assert (!BIG || BLOCK == 2 * TJ_P, "two threads per bucket");
     constexpr int RR = FULL ? PS / BLOCK : R;
@@ -1093,6 +1132,19 @@ struct StageSink
     // never looked at -- and each of the four waves that own buckets works out the whole prefix for itself)
     u64 w[RR][WS], wrem[WS];
     u32 rk[RR], bb[RR], brem = 0;
+    if (gsrc) {
+      if constexpr (W == 1) {
+#pragma unroll
+        for (int r = 0; r < RR; r++) {                  // my records, straight from the log (slots past n: any record of the pass, masked later)
+          const u32 i = (u32) tid + (u32) r * BLOCK;
+          w[r][0] = gsrc[i < n ? i : 0u];
+        }
+#pragma unroll
+        for (int r = 0; r < RR; r++) bb[r] = bucket_of_rec1 ((u32) w[r][0], (u32) (w[r][0] >> 32));
+        PSTAMP (9);
+      }
+    }
+    else
 #pragma unroll
     for (int r = 0; r < RR; r++)                        // my records ...
       if (FULL || (u32) r * BLOCK < n) {
@@ -1135,7 +1187,8 @@ struct StageSink
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK >= 4            // experiment builds only: a private cursor instead of the global atomic (results are wrong)
       if (cnt) { p0 = exp_cur; exp_cur = (p0 + cnt) & 255u; }
 #else
-      if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
+      if constexpr (EXT) { p0 = blk_p0; blk_p0 += cnt; }
+      else if (cnt) p0 = atomicAdd (&B.cursors[tid * TJ_CSTRIDE], cnt);
 #endif
     }
     else if (!FULL && wave == TJ_P / 64) L.offs[tid] = (u32) S + (u32) lane;   // (the spare entries: rank 0 lands on staging slot S + lane)
@@ -1169,7 +1222,7 @@ struct StageSink
       if (cnt) {
 #endif
         const u32 ch = (u32) TJ_CH0 << B.ch_shift;
-        bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
+        if constexpr (!EXT) bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);      // (EXT: whoever reserved the run has claimed for all of it)
         const u32 j0 = chunk_of_pos (B, p0), j1 = chunk_of_pos (B, p0 + cnt - 1);
         if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (B, (u32) tid, j0, true, ctr); }
         if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (B.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch)) * W) - (8ull * W) * off;
@@ -1282,7 +1335,7 @@ struct StageSink
       L.offs[tid] = wbase + incl - cnt;
       // reserve the bucket's run: the global atomic's round trip runs under the LDS permutation below (its result is
       // first looked at after that)
-      if (cnt) p0 = atomicAdd (&B.cursors[tid], cnt);
+      if (cnt) p0 = atomicAdd (&B.cursors[tid * TJ_CSTRIDE], cnt);
     }
     lds_barrier ();
 #pragma unroll
@@ -1406,9 +1459,110 @@ void scan_bins_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_til
 // the run-start plane for the run end, one of the letter plane for "k letters on both sides" (whenever 2k + length <= 32),
 // one of the code plane per flank.
 
+// ---- sink 3: the record log (one-word records: k <= 12) ---------------------------------------------------------------
+// scan_fast_kernel<1> does not partition: a recorded tract goes straight from the lane that worked it out to the next
+// free word of a linear log -- blocks of TJ_LOGB records that a workgroup takes from a counter one ahead of need (the
+// atomic's result is picked up a tile later), slot = the workgroup's running count (one LDS atomic per wave and round, as
+// the staging buffer's was).  partition_log_kernel then reads the log back at memory speed and distributes it over the
+// hash buckets with the counting sort of StageSink::partition_pass -- a kernel of its own with six waves per SIMD, in
+// which that sort's barriers and atomic round trips hide behind other workgroups, instead of a pass that stalls a
+// scanning workgroup 32 times per launch with 37 KB of its LDS and 45 of its registers set aside for it.
+#define TJ_LOGB_SHIFT 13
+#define TJ_LOGB       (1u << TJ_LOGB_SHIFT)             // records per log block (a tile brings at most FK_MAXCAND = 4096)
+#define TJ_LOG_AHEAD  (2u * 4096u + 1024u)              // a block is asked for when the count may reach it within two tiles
+struct LogSpace
+{
+  u64 *log;             // n_blocks * TJ_LOGB records, then 64 scratch words per workgroup of the scan
+  u32 *next;            // blocks handed out
+  u32 *next_other;      // the next launch's counter (launches alternate between two): zeroed by this launch
+  u32 *count;           // [n_blocks] records in each block (written by the workgroup that filled it)
+  u32 n_blocks;
+};
+
+struct LogLds
+{
+  alignas (16) u64 blk[4];              // byte address of the block that holds the workgroup's records j * TJ_LOGB ..., j & 3
+  u32 id[4];
+  u32 n;                                // records appended by this workgroup
+};
+
+struct LogSink
+{
+  static constexpr int S = 0x7FFFFFF0;                  // (no buffer to fill up: every tile "fits")
+  LogLds &L;
+  LogSpace G; DevCounters *ctr;
+  u32 bound;
+  u32 upto, pend, pend_id;                              // thread 0: last block index with an address in L.blk; a reservation on its way
+  u64 scratch;                                          // where lanes without a record write (byte address, 64 words per workgroup)
+
+  __device__ __forceinline__ u64 block_addr (u32 id) const
+  {
+    if (id >= G.n_blocks) { ctr->overflow = 1u; return scratch; }     // (cannot happen: the log is sized for a tract every m' bytes)
+    return (u64) (size_t) G.log + (((u64) id << TJ_LOGB_SHIFT) << 3);
+  }
+  __device__ __forceinline__ void start ()
+  {
+    bound = 0; pend = 0; pend_id = 0; upto = 1;
+    scratch = (u64) (size_t) G.log + ((((u64) G.n_blocks << TJ_LOGB_SHIFT) + 64ull * blockIdx.x) << 3);
+    if (threadIdx.x == 0) {
+      L.n = 0;
+      const u32 b0 = atomicAdd (G.next, 2u);
+      L.id[0] = b0; L.id[1] = b0 + 1u; L.id[2] = ~0u; L.id[3] = ~0u;
+      L.blk[0] = block_addr (b0); L.blk[1] = block_addr (b0 + 1u); L.blk[2] = scratch; L.blk[3] = scratch;
+    }
+    lds_barrier ();
+  }
+  // top of a tile, every outstanding load of the wave waited for: a block that was asked for a tile ago has its address now
+  // (the ring slot it takes held block upto - 3, which is full -- or will be when the kernel ends: slots are handed out densely)
+  __device__ __forceinline__ void collect ()
+  {
+    if (threadIdx.x == 0 && pend) {
+      upto++;
+      const u32 slot = upto & 3u, old = L.id[slot];
+      if (old < G.n_blocks) G.count[old] = TJ_LOGB;
+      L.id[slot] = pend_id; L.blk[slot] = block_addr (pend_id);
+      pend = 0;
+    }
+  }
+  // `n`: the workgroup's count, read while nobody appends
+  __device__ __forceinline__ void tile_top (u32 n)
+  {
+    if (threadIdx.x == 0 && !pend && ((n + TJ_LOG_AHEAD) >> TJ_LOGB_SHIFT) > upto) { pend_id = atomicAdd (G.next, 1u); pend = 1u; }
+  }
+  __device__ __forceinline__ void reserve1 (u32) {}
+  __device__ __forceinline__ u32 count_addr () const { return (u32) (size_t) (lptr_t) &L.n; }
+  __device__ __forceinline__ void store1 (u32 at, u32 lo, u32 hi)
+  {
+    typedef __attribute__((address_space(1))) u64 *gwords_t;
+    *(gwords_t) (L.blk[(at >> TJ_LOGB_SHIFT) & 3u] + 8ull * (at & (TJ_LOGB - 1u))) = ((u64) hi << 32) | lo;
+  }
+  // branch-free: a lane without a record writes to the workgroup's scratch words
+  __device__ __forceinline__ void store1ok (bool ok, u32 at, u32 lo, u32 hi, u32 lane)
+  {
+    typedef __attribute__((address_space(1))) u64 *gwords_t;
+    const u64 a = L.blk[(at >> TJ_LOGB_SHIFT) & 3u] + 8ull * (at & (TJ_LOGB - 1u));
+    *(gwords_t) (ok ? a : scratch + 8ull * lane) = ((u64) hi << 32) | lo;
+  }
+  __device__ __forceinline__ void finish ()
+  {
+    lds_barrier ();
+    collect ();
+    if (threadIdx.x == 0) {
+      const u32 n = L.n;
+      for (u32 j = (upto >= 3u ? upto - 3u : 0u); j <= upto; j++) {
+        const u32 id = L.id[j & 3u];
+        if (id < G.n_blocks) G.count[id] = (n > (j << TJ_LOGB_SHIFT)) ? min (n - (j << TJ_LOGB_SHIFT), TJ_LOGB) : 0u;
+      }
+    }
+  }
+};
+
 #define FK_BLOCK    512
 #ifndef FK_WG_PER_CU
 #define FK_WG_PER_CU 2
+#endif
+#ifndef FK_LOG_WG_PER_CU
+#define FK_LOG_WG_PER_CU 3              // the log variant (no staging buffer: 35 KB of LDS)
 #endif
 // FK_WG_PER_CU: 73 KB of LDS each (the 4096-record staging buffer is worth more than a third workgroup)
 #define FK_UNIT     32                  // stream bytes per lane
@@ -1536,15 +1690,20 @@ __device__ __forceinline__ void lds_dma32 (const uint8_t *sbase, u32 voff, void 
                 :: "v"(voff), "s"(sbase), "{m0}"(m0v) : "memory");
 }
 
-template <int W>
-__global__ __launch_bounds__ (FK_BLOCK, FK_BLOCK * FK_WG_PER_CU / 256)
+template <int W, bool LOG = false>
+__global__ __launch_bounds__ (FK_BLOCK, FK_BLOCK * (LOG ? FK_LOG_WG_PER_CU : FK_WG_PER_CU) / 256)
 void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_ftiles, int k, int mprime,
-                       Buckets BK, DevCounters *ctr, u32 *__restrict__ slow_list, int par, int all_slow)
+                       Buckets BK, DevCounters *ctr, u32 *__restrict__ slow_list, int par, int all_slow, LogSpace LG)
 {
+  static_assert (!LOG || W == 1, "the record log holds one-word records");
   __shared__ FastLds T;
   __shared__ uint4 raw[FK_WIN / 16];
-  __shared__ StageLds<W, true> SL;
-  StageSink<W, FK_BLOCK, true> sink = {SL, BK, ctr, k, 0u, 0u, 0u};
+  __shared__ std::conditional_t<LOG, LogLds, StageLds<W, true>> SL;
+  auto make_sink = [&] () {
+    if constexpr (LOG) return LogSink {SL, LG, ctr, 0u, 0u, 0u, 0u, 0ull};
+    else return StageSink<W, FK_BLOCK, true> {SL, BK, ctr, k, 0u, 0u, 0u};
+  };
+  auto sink = make_sink ();
   sink.start ();
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1582,6 +1741,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       for (int t = 0; t < nt_all; t++) slow_list[t] = (u32) t;
       ctr->lc[par].n_slow = (u32) nt_all; ctr->lc[par].work = (u32) nt_all;
       ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; ctr->lc[par ^ 1].ticket = 0;
+      if constexpr (LOG) *LG.next_other = 0u;
     }
     sink.finish ();
     return;
@@ -1591,7 +1751,10 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   if (wave == 0) {
     if (lane == 0) {
       T.grp[0] = atomicAdd (&ctr->lc[par].work, (u32) FK_GROUP);
-      if (blockIdx.x == 0) { ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; ctr->lc[par ^ 1].ticket = 0; }
+      if (blockIdx.x == 0) {
+        ctr->lc[par ^ 1].n_fix = 0; ctr->lc[par ^ 1].work = 0; ctr->lc[par ^ 1].n_slow = 0; ctr->lc[par ^ 1].work_slow = 0; ctr->lc[par ^ 1].ticket = 0;
+        if constexpr (LOG) *LG.next_other = 0u;
+      }
     }
     if (lane < 4) { T.ncand[lane] = 0; T.bad[lane] = 0; T.code[FK_WIN / 16 + lane] = 0; T.st[FK_WIN / 32 + lane] = 0; T.lt[FK_WIN / 32 + lane] = 0; T.np[FK_WIN / 32 + lane] = 0; T.ncand2 = 0; }
   }
@@ -1758,6 +1921,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
       // the compiler then copies before the word has arrived; through LDS it would cost what it gains, 1.7 %.)
       asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP (1);
+      if constexpr (LOG) sink.collect ();
       const uint4 va = raw[2 * tid], vb = raw[2 * tid + 1];
       x[0] = va.x; x[1] = va.y; x[2] = va.z; x[3] = va.w; x[4] = vb.x; x[5] = vb.y; x[6] = vb.z; x[7] = vb.w;
       if (!((u32) (tile - 1) < (u32) t_hi)) {            // (uniform; the stream's first and last tiles) chunks that are not wholly inside the stream: byte by byte
@@ -1795,6 +1959,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
     // appending this tile's records while a slow one has yet to look (seen: one scan in fifty lost some eighty records
     // when a wave got a larger number, partitioned on its own schedule and its barriers paired up with the others' wrongly)
     const u32 staged_v = SL.n;
+    if constexpr (LOG) sink.tile_top (staged_v);
 #if !(defined(FK_EXP_NOBAR) && (FK_EXP_NOBAR & 2))
     lds_barrier ();
 #endif
@@ -1808,7 +1973,7 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #endif
     // (`bound` has counted candidates, of which one in eight is not recorded -- with the true count the buffer is
     // partitioned when it is full)
-    sink.bound = (u32) __builtin_amdgcn_readfirstlane ((int) staged_v);
+    sink.bound = LOG ? 0u : (u32) __builtin_amdgcn_readfirstlane ((int) staged_v);
 #if defined(FK_EXP_LINEAR)
     sink.bound = 0;
 #endif
@@ -1992,7 +2157,8 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
         }
 #else
         const u32 at = lds_collect (araw) + (u32) __builtin_amdgcn_mbcnt_hi ((u32) (okm >> 32), __builtin_amdgcn_mbcnt_lo ((u32) okm, 0u));
-        sink.store1v (ok ? at : (u32) sink.S + (u32) lane, lo, hi, vh0, vh1, vm27);   // (no record: a spare slot takes the write)
+        if constexpr (LOG) sink.store1ok (ok, at, lo, hi, (u32) lane);
+        else sink.store1v (ok ? at : (u32) sink.S + (u32) lane, lo, hi, vh0, vh1, vm27);   // (no record: a spare slot takes the write)
 #endif
 #endif
         STAMP (7);
@@ -2009,6 +2175,119 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   STAMP_FLUSH;
   flush_slow ();
   sink.finish ();
+}
+
+// The record log of scan_fast_kernel<1, true> -> the hash buckets.  A workgroup takes log blocks in turn (static stride)
+// and runs StageSink's counting sort on PL_S records at a time: the records come straight from HBM (coalesced) into
+// the staging buffer with their bucket, and partition_pass does the rest -- the same reservation protocol on the same
+// bucket cursors and chunk table as every other producer of raw records.
+#define PL_BLOCK 512
+#ifndef PL_WG_PER_CU
+#define PL_WG_PER_CU 2
+#endif
+__global__ __launch_bounds__ (PL_BLOCK, PL_BLOCK * PL_WG_PER_CU / 256)
+void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
+{
+  // One log block (TJ_LOGB records) per pass, two sweeps over it (the second one finds it in L2): count per bucket --
+  // prefix, one reservation per bucket, where the runs go -- then every record straight to its sorted place in LDS (its
+  // rank comes from an LDS atomic on the bucket's running position: no record is held in a register across a barrier) and
+  // the sorted buffer out in runs, coalesced, as StageSink::partition_pass writes them.
+  typedef StageLds<1, 2> Lds;
+  __shared__ Lds L;
+  static_assert (Lds::S == (int) TJ_LOGB, "one pass per log block");
+  constexpr u32 RR = TJ_LOGB / PL_BLOCK;
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 wave = (u32) __builtin_amdgcn_readfirstlane ((int) (tid >> 6));
+  if (tid < TJ_P) L.hist[tid] = 0;
+  u32 cur_j = TJ_EMPTY, cur_chunk = TJ_NOCHUNK;         // owner thread (tid < TJ_P): the chunk its bucket was written to last
+  lds_barrier ();
+  const u32 n_blocks = min (*LG.next, LG.n_blocks);
+  // (blocks in turn, static: a shared work counter would be one more address that every workgroup of the grid adds to)
+  for (u32 b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+    const u32 n = min (LG.count[b], TJ_LOGB);
+    if (n == 0) continue;                                 // (uniform)
+    const u64 *__restrict__ src = LG.log + ((u64) b << TJ_LOGB_SHIFT);
+    // ---- sweep 1: records per bucket
+#pragma unroll
+    for (u32 r0 = 0; r0 < RR; r0 += 8) {
+      if (r0 * PL_BLOCK >= n) break;                      // (uniform)
+      u64 w[8];
+#pragma unroll
+      for (u32 r = 0; r < 8; r++) { const u32 i = tid + (r0 + r) * PL_BLOCK; w[r] = src[i < n ? i : 0u]; }
+#pragma unroll
+      for (u32 r = 0; r < 8; r++) {
+        const u32 i = tid + (r0 + r) * PL_BLOCK;
+        if (i < n) atomicAdd (&L.hist[bucket_of_rec1 ((u32) w[r], (u32) (w[r] >> 32))], 1u);
+      }
+    }
+    lds_barrier ();
+    // ---- owners: prefix, reservation, where the run lives (as in StageSink::partition_pass)
+    if (wave < TJ_P / 64) {
+      const uint4 h4 = *reinterpret_cast<const uint4 *> (&L.hist[4 * lane]);
+      const u32 tot = h4.x + h4.y + h4.z + h4.w;
+      const u32 e0 = wave_inclusive_scan (tot) - tot;
+      if ((lane >> 4) == wave) *reinterpret_cast<uint4 *> (&L.offs[4 * lane]) = make_uint4 (e0, e0 + h4.x, e0 + h4.x + h4.y, e0 + h4.x + h4.y + h4.z);
+      const u32 cnt = L.hist[tid], off = L.offs[tid];
+      u64 a1 = 0, a2 = 0;
+      u32 thr = off + cnt;
+      if (cnt) {
+        const u32 p0 = atomicAdd (&BK.cursors[tid * TJ_CSTRIDE], cnt);
+        const u32 ch = (u32) TJ_CH0 << BK.ch_shift;
+        bucket_claim_ahead_range (BK, tid, p0, cnt, ctr);   // (a run of up to TJ_LOGB records may hold more than one chunk's first record)
+        const u32 j0 = chunk_of_pos (BK, p0), j1 = chunk_of_pos (BK, p0 + cnt - 1);
+        if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (BK, tid, j0, true, ctr); }
+        if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch))) - 8ull * off;
+        if (j1 != j0) {                                   // the run crosses into the next chunk (chunks are longer than a log block: at most once)
+          thr = off + ((j0 + 1u) * ch - p0);
+          cur_j = j0 + 1u; cur_chunk = bucket_chunk_id (BK, tid, j0 + 1u, true, ctr);
+          if (cur_chunk != TJ_NOCHUNK) a2 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch)) - 8ull * thr;
+        }
+      }
+      reinterpret_cast<uint4 *> (L.gbase)[tid] = make_uint4 ((u32) a1, (u32) (a1 >> 32) | (thr << 16), (u32) a2, (u32) (a2 >> 32));
+    }
+    lds_barrier ();
+    if (tid < TJ_P) L.hist[tid] = 0;                      // (for the next block; sweep 2 counts in offs)
+    // ---- sweep 2: every record to its sorted slot (offs[bucket] runs from the bucket's first slot to its last)
+#pragma unroll
+    for (u32 r0 = 0; r0 < RR; r0 += 8) {
+      if (r0 * PL_BLOCK >= n) break;
+      u64 w[8];
+#pragma unroll
+      for (u32 r = 0; r < 8; r++) { const u32 i = tid + (r0 + r) * PL_BLOCK; w[r] = src[i < n ? i : 0u]; }
+#pragma unroll
+      for (u32 r = 0; r < 8; r++) {
+        const u32 i = tid + (r0 + r) * PL_BLOCK;
+        if (i < n) {
+          const u32 bin = bucket_of_rec1 ((u32) w[r], (u32) (w[r] >> 32));
+          const u32 d = atomicAdd (&L.offs[bin], 1u);
+          L.rec[d] = w[r];
+          L.bin[d] = (unsigned char) bin;
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt (0x0F70);                  // vmcnt(0): nothing but the stores below in flight from here on
+    lds_barrier ();
+    // ---- copy-out: sorted slot i -> its place in the bucket's run
+#pragma unroll
+    for (u32 r0 = 0; r0 < RR; r0 += 4) {
+      if (r0 * PL_BLOCK >= n) break;
+      u32 cb[4]; uint4 e[4]; u64 cw[4];
+#pragma unroll
+      for (u32 h = 0; h < 4; h++) cb[h] = L.bin[tid + (r0 + h) * PL_BLOCK];
+#pragma unroll
+      for (u32 h = 0; h < 4; h++) { e[h] = reinterpret_cast<const uint4 *> (L.gbase)[cb[h]]; cw[h] = L.rec[tid + (r0 + h) * PL_BLOCK]; }
+#pragma unroll
+      for (u32 h = 0; h < 4; h++) {
+        const u32 i = tid + (r0 + h) * PL_BLOCK;
+        const u64 a = (i < (e[h].y >> 16)) ? (((u64) (e[h].y & 0xFFFFu) << 32) | e[h].x) : (((u64) e[h].w << 32) | e[h].z);
+        if (i < n && a != 0ull) {
+          typedef __attribute__((address_space(1))) u64 *gwords_t;
+          *(gwords_t) (a + 8ull * i) = cw[h];
+        }
+      }
+    }
+    lds_barrier ();                                       // the sorted buffer is free again
+  }
 }
 
 template <int W>
@@ -2034,7 +2313,7 @@ template <int W>
 __global__ void unpack_buckets_kernel (Buckets BK, int k, u64 *__restrict__ out, u64 cap, u64 *n_out)
 {
   const u32 b = blockIdx.x;
-  const u32 n = BK.cursors[b];
+  const u32 n = BK.cursors[b * TJ_CSTRIDE];
   for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
     u64 c0, c1; u32 base, len10, flag;
     const u64 at = bucket_slot (BK, b, i, false, nullptr);
@@ -2063,9 +2342,9 @@ __global__ void clear_buckets_kernel (u32 *cursors, DevCounters *ctr, u32 *table
   const u32 b = blockIdx.x;
   if (snap_ctr) {                                       // (every workgroup reads its own cursor, workgroup 0 the rest: before anything is zeroed)
     if (threadIdx.x == 0) {
-      snap_cursors[b] = cursors[b];
+      snap_cursors[b] = cursors[b * TJ_CSTRIDE];
       if (b == 0) {
-        snap_cursors[TJ_P] = cursors[TJ_P];
+        snap_cursors[TJ_P] = cursors[TJ_P * TJ_CSTRIDE];
         // The kept count and the overflow flag as a kernel boundary shows them.  plan_tail read them inside the
         // aggregation, from its last workgroup, through relaxed atomics and no fence (a fence there doubled the kernel's
         // time): the host compares the two readings and runs the ordering step again if they ever differ.
@@ -2080,7 +2359,7 @@ __global__ void clear_buckets_kernel (u32 *cursors, DevCounters *ctr, u32 *table
   if (b == 0) for (u32 i = threadIdx.x; i < sizeof (DevCounters) / 4; i += blockDim.x) if (i != offsetof (DevCounters, n_undefined) / 4 && i != offsetof (DevCounters, n_undefined) / 4 + 1) reinterpret_cast<u32 *> (ctr)[i] = 0;
   if (table) {
     u32 used = maxj;
-    if (ch_shift >= 0) used = min (maxj, ((cursors[b] / TJ_CH0) >> ch_shift) + 3u);
+    if (ch_shift >= 0) used = min (maxj, ((cursors[b * TJ_CSTRIDE] / TJ_CH0) >> ch_shift) + 3u);
     for (u32 j = threadIdx.x; j < used; j += blockDim.x) table[(u64) b * maxj + j] = j ? TJ_EMPTY : b;
   }
   if (fine) {
@@ -2110,7 +2389,7 @@ __global__ void clear_buckets_kernel (u32 *cursors, DevCounters *ctr, u32 *table
   }
   else if (bins) for (int i = (int) (b * blockDim.x + threadIdx.x); i < nbins; i += (int) (gridDim.x * blockDim.x)) bins[i] = 0;
   __syncthreads ();
-  if (threadIdx.x == 0) { cursors[b] = 0; if (b == 0) { cursors[TJ_P] = TJ_P; fin->n_kept = 0; fin->overflow = 0; fin->pad = 0; } }
+  if (threadIdx.x == 0) { cursors[b * TJ_CSTRIDE] = 0; if (b == 0) { cursors[TJ_P * TJ_CSTRIDE] = TJ_P; fin->n_kept = 0; fin->overflow = 0; fin->pad = 0; } }
 }
 
 // chunk table with a longer row
@@ -2208,7 +2487,7 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
   __shared__ Agg1Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 bkt = blockIdx.x;
-  u32 n = BK.cursors[bkt];
+  u32 n = BK.cursors[bkt * TJ_CSTRIDE];
   if (n) for (u32 j = (u32) tid; j <= chunk_of_pos (BK, n - 1u) && j < AG_NCH; j += AG_BLOCK) L.chunk[j] = bucket_chunk_id (BK, bkt, j, false, nullptr);
   auto chunk_id = [&] (u32 j) { return j < AG_NCH ? L.chunk[j] : bucket_chunk_id (BK, bkt, j, false, nullptr); };
 
@@ -2468,7 +2747,7 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
   __shared__ Agg2Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 bkt = blockIdx.x;
-  u32 n = BK.cursors[bkt];
+  u32 n = BK.cursors[bkt * TJ_CSTRIDE];
   const u64 m56 = (1ull << 56) - 1ull, fmask = ~(3ull << 61);
   if (n) for (u32 j = (u32) tid; j <= chunk_of_pos (BK, n - 1u) && j < AG_NCH; j += AG_BLOCK) L.chunk[j] = bucket_chunk_id (BK, bkt, j, false, nullptr);
   auto chunk_id = [&] (u32 j) { return j < AG_NCH ? L.chunk[j] : bucket_chunk_id (BK, bkt, j, false, nullptr); };
@@ -2704,7 +2983,7 @@ void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
   __shared__ Agg4Lds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 bkt = blockIdx.x;
-  u32 n = BK.cursors[bkt];
+  u32 n = BK.cursors[bkt * TJ_CSTRIDE];
   if (n) for (u32 j = (u32) tid; j <= chunk_of_pos (BK, n - 1u) && j < AG_NCH; j += AG_BLOCK) L.chunk[j] = bucket_chunk_id (BK, bkt, j, false, nullptr);
   auto chunk_id = [&] (u32 j) { return j < AG_NCH ? L.chunk[j] : bucket_chunk_id (BK, bkt, j, false, nullptr); };
   const u64 *src = BK.pool;
@@ -3742,6 +4021,11 @@ struct tjamd_counter
   DevCounters *d_lctr = nullptr;                      // located-list counters
   u32 *d_cursors = nullptr, *h_cursors = nullptr;     // [TJ_P] records per bucket, then [TJ_P] = next free chunk
   DevBuf pool, table, stage, fix, loc, prefix, rawlist, slow;
+  DevBuf log, logmeta;        // the record log of scan_fast_kernel<1, true> and its block counters (2 words: blocks handed out, by launch parity; then a count per block)
+  bool log_mode = true;       // k <= 12: the fast kernel writes a log and partition_log_kernel fills the buckets (TATAJUBA_AMD_SINK=fused: the kernel partitions by itself)
+  bool log_next_clean[2] = {false, false};
+  hipEvent_t ev_p1 = nullptr; // after the partition kernel of the last scan call
+  bool part_timed = false;
   int fast_mode = 1;          // 1: scan_fast_kernel + the generic kernel on what it leaves; 0: generic kernel only; 2: fast kernel leaves everything (tests)
   u32 pool_chunks = 0, maxj = 0;
   int ch_shift = -1;          // chunk = TJ_CH0 << ch_shift records; fixed by the first scan after a reset
@@ -3813,6 +4097,8 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   if (bm && atoi (bm) >= 1 && atoi (bm) <= BS_RANK_MAX) c->bin_rank_max = (u32) atoi (bm);
   const char *pc = getenv ("TATAJUBA_AMD_SCAN_PIECE");
   if (pc && atol (pc) >= 4096) c->piece_target = (size_t) atol (pc);
+  const char *sk = getenv ("TATAJUBA_AMD_SINK");          // "fused": scan_fast_kernel<1> partitions its records itself (rounds 1-3); default: record log + partition_log_kernel
+  if (sk && !strcmp (sk, "fused")) c->log_mode = false;
   const char *fm = getenv ("TATAJUBA_AMD_FAST");          // test hook: 0 = generic scan kernel only, 2 = fast kernel hands every tile over
   if (fm && atoi (fm) >= 0 && atoi (fm) <= 2) c->fast_mode = atoi (fm);
   const char *sl = getenv ("TATAJUBA_AMD_BUCKET_SLACK");
@@ -3822,13 +4108,16 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   HIPCHK_NULL (hipMalloc ((void **) &c->d_state, sizeof (DevState)));
   HIPCHK_NULL (hipMalloc ((void **) &c->d_lctr, sizeof (DevCounters)));
   HIPCHK_NULL (hipHostMalloc ((void **) &c->h_state, sizeof (DevState), hipHostMallocDefault));
-  c->d_ctr = &c->d_state->ctr; c->d_fin = &c->d_state->fin; c->d_cursors = c->d_state->cursors;
+  c->d_ctr = &c->d_state->ctr; c->d_fin = &c->d_state->fin;
+  HIPCHK_NULL (hipMalloc ((void **) &c->d_cursors, (size_t) (TJ_P + 1) * TJ_CSTRIDE * 4));     // (strided: see TJ_CSTRIDE; d_state->cursors is the packed copy the host reads)
+  HIPCHK_NULL (hipMemsetAsync (c->d_cursors, 0, (size_t) (TJ_P + 1) * TJ_CSTRIDE * 4, c->stream));
   c->h_ctr = &c->h_state->ctr; c->h_fin = &c->h_state->fin; c->h_cursors = c->h_state->cursors;
   memset (c->h_state, 0, sizeof (DevState));
   HIPCHK_NULL (hipMemsetAsync (c->d_state, 0, sizeof (DevState), c->stream));
   HIPCHK_NULL (hipMemsetAsync (c->d_lctr, 0, sizeof (DevCounters), c->stream));
   HIPCHK_NULL (hipEventCreate (&c->ev_s0)); HIPCHK_NULL (hipEventCreate (&c->ev_s1));
   HIPCHK_NULL (hipEventCreate (&c->ev_f0)); HIPCHK_NULL (hipEventCreate (&c->ev_f1));
+  HIPCHK_NULL (hipEventCreate (&c->ev_p1));
   HIPCHK_NULL (hipEventCreateWithFlags (&c->ev_done, hipEventDisableTiming));
   HIPCHK_NULL (hipEventCreateWithFlags (&c->ev_agg, hipEventDisableTiming));
   HIPCHK_NULL (hipStreamSynchronize (c->stream));
@@ -3840,16 +4129,18 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   if (!c) return;
   (void) hipSetDevice (c->device);
   (void) hipStreamSynchronize (c->stream);
-  DevBuf *all[] = {&c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->slow, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
+  DevBuf *all[] = {&c->log, &c->logmeta, &c->pool, &c->table, &c->stage, &c->fix, &c->loc, &c->prefix, &c->rawlist, &c->slow, &c->alt, &c->hist, &c->flags, &c->segid, &c->headpos,
                    &c->keep, &c->outpos, &c->scan_tmp, &c->kept, &c->idx_i, &c->idx_f, &c->cov, &c->bins, &c->binstart, &c->binctx, &c->ovf, &c->grp_jt, &c->grp_hist, &c->fine};
   for (DevBuf *b : all) release (*b);
   for (hipEvent_t ev : c->marks) if (ev) (void) hipEventDestroy (ev);
   if (c->d_state) (void) hipFree (c->d_state);
   if (c->d_lctr) (void) hipFree (c->d_lctr);
+  if (c->d_cursors) (void) hipFree (c->d_cursors);
   if (c->h_state) (void) hipHostFree (c->h_state);
   if (c->h_kept) (void) hipHostFree (c->h_kept);
   if (c->ev_s0) (void) hipEventDestroy (c->ev_s0);
   if (c->ev_s1) (void) hipEventDestroy (c->ev_s1);
+  if (c->ev_p1) (void) hipEventDestroy (c->ev_p1);
   if (c->ev_f0) (void) hipEventDestroy (c->ev_f0);
   if (c->ev_f1) (void) hipEventDestroy (c->ev_f1);
   if (c->ev_done) (void) hipEventDestroy (c->ev_done);
@@ -3886,7 +4177,7 @@ extern "C" int tjamd_counter_set_order_stream (tjamd_counter *c, void *hip_strea
 static Buckets make_buckets (const tjamd_counter *c)
 {
   Buckets B;
-  B.pool = (u64 *) c->pool.p; B.table = (u32 *) c->table.p; B.cursors = c->d_cursors; B.pool_next = c->d_cursors + TJ_P;
+  B.pool = (u64 *) c->pool.p; B.table = (u32 *) c->table.p; B.cursors = c->d_cursors; B.pool_next = c->d_cursors + TJ_P * TJ_CSTRIDE;
   B.pool_chunks = c->pool_chunks; B.maxj = c->maxj; B.ch_shift = (u32) std::max (c->ch_shift, 0);
   return B;
 }
@@ -3982,8 +4273,15 @@ extern "C" int tjamd_wait_mark (tjamd_counter *c, int mark)
 }
 
 // stream synchronisation + exact counts
+__global__ void pack_cursors_kernel (const u32 *__restrict__ cursors, u32 *__restrict__ packed)
+{
+  if (threadIdx.x <= TJ_P) packed[threadIdx.x] = cursors[threadIdx.x * TJ_CSTRIDE];
+}
+
 static int queue_counter_copies (tjamd_counter *c)
 {
+  hipLaunchKernelGGL (pack_cursors_kernel, dim3 (1), dim3 (320), 0, c->stream, (const u32 *) c->d_cursors, c->d_state->cursors);
+  HIPCHK (hipGetLastError ());
   HIPCHK (hipMemcpyAsync (c->h_state, c->d_state, sizeof (DevState), hipMemcpyDeviceToHost, c->stream));
   return TJAMD_OK;
 }
@@ -4025,7 +4323,8 @@ static void choose_chunk_size (tjamd_counter *c, u64 records)
 { // fixed by the first scan (or reservation) after a reset: at most ~16 k chunks for this many records
   if (c->ch_shift >= 0) return;
   const u64 units = records / (16384ull * TJ_CH0);
-  int sft = 2;                                          // a chunk holds more than one partition pass stages (4096 records)
+  int sft = 3;                                          // a chunk holds more than any one reservation: a partition pass stages 4096 records, partition_log_kernel's TJ_LOGB = 8192
+  static_assert ((TJ_CH0 << 3) > (int) TJ_LOGB, "a run of one log block crosses at most one chunk boundary");
   while ((1ull << sft) < units) sft++;
   c->ch_shift = sft;
 }
@@ -4040,7 +4339,7 @@ static int ensure_table (tjamd_counter *c, u64 need_maxj)
     if (e != hipSuccess) return set_err (TJAMD_ERR_HIP, "hipMalloc of the chunk table failed: %s", hipGetErrorString (e));
     HIPCHK (hipMemsetAsync (np, 0xFF, (size_t) TJ_P * nmaxj * 4, c->stream));
     if (!c->table.p || !c->maxj) {
-      hipLaunchKernelGGL (init_table_kernel, dim3 (1), dim3 (TJ_P), 0, c->stream, (u32 *) np, nmaxj, c->d_cursors + TJ_P);
+      hipLaunchKernelGGL (init_table_kernel, dim3 (1), dim3 (TJ_P), 0, c->stream, (u32 *) np, nmaxj, c->d_cursors + TJ_P * TJ_CSTRIDE);
       HIPCHK (hipGetLastError ());
     }
     if (c->table.p) {
@@ -4139,11 +4438,34 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
   // (the fast kernel counts tiles and bytes in 32 bits: a piece that could not be cut below 2 GiB -- one read longer
   // than that -- is left to the general kernel)
   const bool use_fast = c->fast_mode && n_bytes < ((size_t) 1 << 31) - (1u << 20);
+  // one-word records (k <= 12): the fast kernel appends to a log sized for the worst case (a tract every m' bytes; every
+  // workgroup leaves at most two blocks partly filled), partition_log_kernel distributes it over the buckets
+  const bool use_log = use_fast && c->W == 1 && c->log_mode;
+  LogSpace LG = {nullptr, nullptr, nullptr, 0u};
+  const int fgrid_log = (int) std::min<long> (n_ftiles, (long) c->n_cu * FK_LOG_WG_PER_CU);
+  if (use_log) {
+    const u64 n_blocks = (bound >> TJ_LOGB_SHIFT) + 2ull * (u64) fgrid_log + 4ull;
+    rc = ensure (c->log, (size_t) (((n_blocks << TJ_LOGB_SHIFT) + 64ull * (u64) fgrid_log) * 8ull), c->stream);
+    if (!rc && (size_t) (n_blocks + 2) * 4 > c->logmeta.cap) {
+      rc = ensure (c->logmeta, (size_t) (n_blocks + 2) * 4 * 2, c->stream);
+      c->log_next_clean[0] = c->log_next_clean[1] = false;
+    }
+    if (rc) return rc;
+    u32 *meta = (u32 *) c->logmeta.p;
+    if (!c->log_next_clean[par]) HIPCHK (hipMemsetAsync (meta + par, 0, 4, c->stream));
+    LG.log = (u64 *) c->log.p; LG.next = meta + par; LG.next_other = meta + (par ^ 1); LG.count = meta + 2; LG.n_blocks = (u32) n_blocks;
+    c->log_next_clean[par] = false; c->log_next_clean[par ^ 1] = true;
+  }
+  else c->log_next_clean[par ^ 1] = c->log_next_clean[par ^ 1] && true;
 #define TJ_LAUNCH_SCAN(WW) do { \
     if (use_fast) { \
       /* the fast kernel takes every tile it can vouch for and lists the others; the generic kernel then works through the list */ \
+      if (WW == 1 && use_log) \
+        hipLaunchKernelGGL ((scan_fast_kernel<1, true>), dim3 (fgrid_log), dim3 (FK_BLOCK), 0, c->stream, seq, (long) n_bytes, n_ftiles, c->k, mprime, BK, c->d_ctr, \
+                            (u32 *) c->slow.p, par, c->fast_mode == 2 ? 1 : 0, LG); \
+      else \
       hipLaunchKernelGGL (scan_fast_kernel<WW>, dim3 (fgrid), dim3 (FK_BLOCK), 0, c->stream, seq, (long) n_bytes, n_ftiles, c->k, mprime, BK, c->d_ctr, \
-                          (u32 *) c->slow.p, par, c->fast_mode == 2 ? 1 : 0); \
+                          (u32 *) c->slow.p, par, c->fast_mode == 2 ? 1 : 0, LG); \
       const TileSrc listed = {(const u32 *) c->slow.p, (long) FK_OWN}; \
       hipLaunchKernelGGL (scan_bins_kernel<WW>, dim3 (lgrid), dim3 (TJ_SB_BLOCK), 0, c->stream, seq, (long) n_bytes, 0l, c->k, mprime, BK, c->d_ctr, fix, (u32) TJ_FIX_CAP, par, listed); \
     } \
@@ -4160,6 +4482,11 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
 #undef TJ_LAUNCH_SCAN
   HIPCHK (hipGetLastError ());
   if (last) HIPCHK (hipEventRecord (c->ev_s1, c->stream));
+  if (use_log) {
+    hipLaunchKernelGGL (partition_log_kernel, dim3 ((unsigned) (c->n_cu * PL_WG_PER_CU)), dim3 (PL_BLOCK), 0, c->stream, LG, BK, c->d_ctr, c->k);
+    HIPCHK (hipGetLastError ());
+  }
+  if (last) { HIPCHK (hipEventRecord (c->ev_p1, c->stream)); c->part_timed = use_log; }
   c->scan_timed = true;
   c->last_scan_launches = first ? 1 : c->last_scan_launches + 1;
   c->status = -1;
@@ -4706,6 +5033,15 @@ extern "C" double tjamd_last_scan_ms (tjamd_counter *c)
   if (!c || !c->scan_timed) return -1.0;
   float ms = 0.f;
   if (hipSetDevice (c->device) != hipSuccess || hipEventSynchronize (c->ev_s1) != hipSuccess || hipEventElapsedTime (&ms, c->ev_s0, c->ev_s1) != hipSuccess) return -1.0;
+  return (double) ms;
+}
+
+extern "C" double tjamd_last_partition_ms (tjamd_counter *c)
+{ // partition_log_kernel behind the last scan launch (k <= 12, record log); 0 when the scan partitioned by itself
+  if (!c || !c->scan_timed) return -1.0;
+  if (!c->part_timed) return 0.0;
+  float ms = 0.f;
+  if (hipSetDevice (c->device) != hipSuccess || hipEventSynchronize (c->ev_p1) != hipSuccess || hipEventElapsedTime (&ms, c->ev_s1, c->ev_p1) != hipSuccess) return -1.0;
   return (double) ms;
 }
 

@@ -18,6 +18,7 @@ for it in range(int(os.environ.get("TJ_REPS", "6"))):
     except tj.TatajubaAmdError as e:           # (ablated builds may trip the capacity checks: the time still counts)
         print("error:", str(e)[:60])
     ms.append(c.last_scan_ms())
+    pm = c.last_partition_ms() if hasattr(c, "last_partition_ms") else 0.0
 print(os.environ.get("TJ_DIAG_LIB"), "fast", os.environ.get("TATAJUBA_AMD_FAST", "1"), "scan ms", " ".join("%.3f" % x for x in ms), "raw", (c.raw_count() if not os.environ.get("TJ_NORAW") else -1),
-      "GB/s %.0f" % (s.size / min(ms[1:]) / 1e6))
+      "GB/s %.0f" % (s.size / min(ms[1:]) / 1e6), "partition ms %.3f" % pm)
 c.close()      # (before the interpreter starts taking modules apart: the counter owns a stream and device buffers)

@@ -1,0 +1,51 @@
+// micro-benchmark 7: what the write pattern of a hash partition costs -- 256 bucket frontiers, every workgroup writes one run
+// of R eight-byte records to each of them per pass (sorted slots -> coalesced stores, as StageSink's copy-out does); runs of
+// a bucket lie back to back.  R = 14: runs start and end inside 128-byte lines that another workgroup's run shares (what
+// the partition writes); R = 16: whole lines; "14 of 16": line-aligned runs that leave the last two records of their line
+// unwritten (partial lines, but nobody else's).  Reports GB/s of records written.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef unsigned long long u64;
+typedef unsigned u32;
+template <int R, int STRIDE>
+__global__ __launch_bounds__ (512) void write_runs (u64 *pool, u64 region_words, u32 passes)
+{
+  constexpr int N = 256 * R;
+  for (u32 p = blockIdx.x; p < passes; p += gridDim.x)
+    for (int i = threadIdx.x; i < N; i += 512) {
+      const u32 b = (u32) i / R, o = (u32) i % R;
+      pool[(u64) b * region_words + (u64) p * STRIDE + o] = ((u64) p << 32) | (u32) i | 1u;
+    }
+}
+template <int R, int STRIDE>
+static void run (const char *what, u64 *pool, u64 region_words, u64 records)
+{
+  const u32 passes = (u32) (records / (256 * R));
+  hipEvent_t e0, e1; hipEventCreate (&e0); hipEventCreate (&e1);
+  float best = 1e9f;
+  for (int it = 0; it < 5; it++) {
+    hipEventRecord (e0);
+    write_runs<R, STRIDE><<<768, 512>>> (pool, region_words, passes);
+    hipEventRecord (e1); hipEventSynchronize (e1);
+    float ms; hipEventElapsedTime (&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  printf ("%-34s R %3d stride %3d: %.3f ms for %.0f M records = %.0f GB/s of records\n", what, R, STRIDE, best, passes * 256.0 * R / 1e6, passes * 256.0 * R * 8 / best / 1e6);
+}
+int main ()
+{
+  const u64 records = 60000000ull, region_words = records / 256 * 2 + 4096;
+  u64 *pool; if (hipMalloc (&pool, 256 * region_words * 8) != hipSuccess) { printf ("alloc failed\n"); return 1; }
+  hipMemset (pool, 0, 256 * region_words * 8);
+  run<14, 14> ("runs of 14, back to back", pool, region_words, records);
+  run<16, 16> ("runs of 16 = whole lines", pool, region_words, records);
+  run<14, 16> ("14 of every 16 (aligned, partial)", pool, region_words, records);
+  run<28, 28> ("runs of 28, back to back", pool, region_words, records);
+  run<32, 32> ("runs of 32", pool, region_words, records);
+  run<60, 60> ("runs of 60, back to back", pool, region_words, records);
+  run<64, 64> ("runs of 64", pool, region_words, records);
+  run<15, 15> ("runs of 15, back to back", pool, region_words, records);
+  run<8, 8> ("runs of 8 = half lines", pool, region_words, records);
+  return 0;
+}
