@@ -374,7 +374,7 @@ def main():
         st = cnt.finalise_end()
         if st != 0:
             raise SystemExit(f"finalise status {st}")
-        times.append((cnt.last_scan_ms(), cnt.last_finalise_ms()))
+        times.append((cnt.last_scan_ms(), cnt.last_finalise_ms(), cnt.last_partition_ms()))
 
     def step():
         nonlocal pending, begun, n_step, c
@@ -421,7 +421,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     assert len(times) == args.steps
-    scan_ms, fin_ms = [a for a, _ in times], [b for _, b in times]
+    scan_ms, fin_ms, part_ms = [t[0] for t in times], [t[1] for t in times], [t[2] for t in times]
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -430,6 +430,7 @@ def main():
     kept = c.n_kept
     scan_avg = float(np.mean(scan_ms))
     fin_avg = float(np.mean(fin_ms))
+    part_avg = float(np.mean(part_ms))
     total_reads = args.reads * world * args.steps
     value = total_reads / dt
 
@@ -445,7 +446,8 @@ def main():
     dominant = "scan" if scan_avg >= fin_avg else "finalise"
     # HBM bytes per launch from the PMC passes of the same command (tools/pmc_traffic.py -> profiles/; rocprofv3 cannot
     # run inside the timed process), only when they were taken on this workload
-    scan_kernel = "scan_fast_kernel<%d>" % (1 if k <= 12 else (2 if k <= 28 else 4))
+    uses_log = c.uses_log()
+    scan_kernel = "scan_fast_kernel<1, true>" if uses_log else "scan_fast_kernel<%d, false>" % (1 if k <= 12 else (2 if k <= 28 else 4))
     traffic, traffic_src = None, None
     import glob
     for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):     # the latest round's passes first
@@ -487,6 +489,14 @@ def main():
                             "note": "stream resident in HBM (the throughput `value` is quoted on)"},
                    "finalise": {"ms": fin_avg, "algorithmic_GBps": fin_gbs, "frac_of_hbm_peak": fin_gbs / HBM_PEAK_GBS}},
     }
+    if uses_log:
+        # k <= 12: the scan kernel appends its records to a linear log, partition_log_kernel distributes the log over the hash
+        # buckets (its algorithmic bytes: every record read once and written once)
+        part_bytes = 2.0 * wbytes * raw
+        out["stages"]["partition"] = {"ms": part_avg, "kernel": "partition_log_kernel", "algorithmic_bytes": part_bytes,
+                                      "algorithmic_GBps": part_bytes / (part_avg * 1e-3) / 1e9, "frac_of_hbm_peak": part_bytes / (part_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "record log -> hash buckets, between the scan and the finalise; TATAJUBA_AMD_SINK=fused makes the scan kernel partition "
+                                              "by itself instead (rounds 1-3: a shorter step, the scan kernel at a third of the HBM peak)"}
 
     if rank == 0 and world == 1:
         # what a C caller of the drop-in API gets per sample once its reads are in HBM: the scan, the whole of

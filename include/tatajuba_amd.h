@@ -203,6 +203,7 @@ void tjamd_thread_cleanup (void);
 
 /* timing of the last operations on this counter, from HIP events on its stream (milliseconds) */
 double tjamd_last_scan_ms (tjamd_counter *c);       /* scan kernel(s) of the last tjamd_scan_* call */
+int    tjamd_counter_uses_log (const tjamd_counter *c);  /* 1: k <= 12 and the scan writes a record log that partition_log_kernel distributes (default); 0: the scan kernels partition by themselves (k > 12, or TATAJUBA_AMD_SINK=fused) */
 double tjamd_last_partition_ms (tjamd_counter *c);  /* partition_log_kernel behind the last scan launch (k <= 12); 0 if the scan kernel partitioned by itself */
 double tjamd_last_finalise_ms (tjamd_counter *c);   /* whole device finalise of the last tjamd_finalise call */
 long   tjamd_last_scan_launches (tjamd_counter *c);

@@ -2188,106 +2188,131 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 __global__ __launch_bounds__ (PL_BLOCK, PL_BLOCK * PL_WG_PER_CU / 256)
 void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
 {
-  // One log block (TJ_LOGB records) per pass, two sweeps over it (the second one finds it in L2): count per bucket --
-  // prefix, one reservation per bucket, where the runs go -- then every record straight to its sorted place in LDS (its
-  // rank comes from an LDS atomic on the bucket's running position: no record is held in a register across a barrier) and
-  // the sorted buffer out in runs, coalesced, as StageSink::partition_pass writes them.
+  // One log block (TJ_LOGB records, 16 per thread) per pass, the records in registers from the load to their place in the
+  // sorted buffer: count per bucket (LDS atomics) -- prefix, one reservation per bucket, where the runs go (the owners, as
+  // in StageSink::partition_pass) -- every record straight to its sorted slot in LDS (its rank: an LDS atomic on the
+  // bucket's running position) -- the sorted buffer out in runs, coalesced.  Four barriers per 8192 records; two
+  // workgroups per CU cover each other's waits.  What bounds it is the memory system: 0.48 GB read in a line, 0.48 GB
+  // written in runs of 32 records to 256 places (tools/ubench/write_runs.hip: that write pattern alone takes 0.16 ms);
+  // loading the next block's records while this one is sorted and written changed nothing (tried, with 32 more registers).
   typedef StageLds<1, 2> Lds;
   __shared__ Lds L;
   static_assert (Lds::S == (int) TJ_LOGB, "one pass per log block");
   constexpr u32 RR = TJ_LOGB / PL_BLOCK;
+  static_assert (RR == 16, "bins are kept four to a register");
   const u32 tid = threadIdx.x, lane = tid & 63u;
   const u32 wave = (u32) __builtin_amdgcn_readfirstlane ((int) (tid >> 6));
   if (tid < TJ_P) L.hist[tid] = 0;
   u32 cur_j = TJ_EMPTY, cur_chunk = TJ_NOCHUNK;         // owner thread (tid < TJ_P): the chunk its bucket was written to last
   lds_barrier ();
   const u32 n_blocks = min (*LG.next, LG.n_blocks);
+#if TJ_STAMPS == 2
+  Stamper stamper; stamper.begin ();
+#endif
   // (blocks in turn, static: a shared work counter would be one more address that every workgroup of the grid adds to)
-  for (u32 b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-    const u32 n = min (LG.count[b], TJ_LOGB);
-    if (n == 0) continue;                                 // (uniform)
-    const u64 *__restrict__ src = LG.log + ((u64) b << TJ_LOGB_SHIFT);
-    // ---- sweep 1: records per bucket
+  u32 b = blockIdx.x;
+  if (b >= n_blocks) return;
+  u64 w[RR];
+  u32 n = LG.count[b], nn = 0;
+  {
+    const u64 *__restrict__ src = LG.log + ((u64) b << TJ_LOGB_SHIFT);    // (a block is TJ_LOGB words of the log whatever its count: no load depends on it)
 #pragma unroll
-    for (u32 r0 = 0; r0 < RR; r0 += 8) {
-      if (r0 * PL_BLOCK >= n) break;                      // (uniform)
-      u64 w[8];
+    for (u32 r = 0; r < RR; r++) w[r] = (src + r * PL_BLOCK)[tid];
+  }
+  while (true) {
+    const u32 bn = b + gridDim.x;
+    const bool more = bn < n_blocks;                      // (uniform)
+    n = min (n, TJ_LOGB);
+    PLSTAMP (0);
+    u32 tq = tid;
+    asm volatile ("" : "+v"(tq));                         // (opaque: what the compiler can derive from tid alone it hoists out of the loop -- sixteen 64-bit offsets 8 i took 32 registers and went to scratch)
+    u32 pk[RR / 4] = {0, 0, 0, 0};
+    if (n) {
+      // ---- records per bucket
 #pragma unroll
-      for (u32 r = 0; r < 8; r++) { const u32 i = tid + (r0 + r) * PL_BLOCK; w[r] = src[i < n ? i : 0u]; }
-#pragma unroll
-      for (u32 r = 0; r < 8; r++) {
-        const u32 i = tid + (r0 + r) * PL_BLOCK;
-        if (i < n) atomicAdd (&L.hist[bucket_of_rec1 ((u32) w[r], (u32) (w[r] >> 32))], 1u);
+      for (u32 r = 0; r < RR; r++) {
+        const u32 bin = bucket_of_rec1 ((u32) w[r], (u32) (w[r] >> 32));
+        pk[r >> 2] |= bin << (8u * (r & 3u));
+        if (tid + r * PL_BLOCK < n) atomicAdd (&L.hist[bin], 1u);
       }
     }
-    lds_barrier ();
-    // ---- owners: prefix, reservation, where the run lives (as in StageSink::partition_pass)
-    if (wave < TJ_P / 64) {
-      const uint4 h4 = *reinterpret_cast<const uint4 *> (&L.hist[4 * lane]);
-      const u32 tot = h4.x + h4.y + h4.z + h4.w;
-      const u32 e0 = wave_inclusive_scan (tot) - tot;
-      if ((lane >> 4) == wave) *reinterpret_cast<uint4 *> (&L.offs[4 * lane]) = make_uint4 (e0, e0 + h4.x, e0 + h4.x + h4.y, e0 + h4.x + h4.y + h4.z);
-      const u32 cnt = L.hist[tid], off = L.offs[tid];
-      u64 a1 = 0, a2 = 0;
-      u32 thr = off + cnt;
-      if (cnt) {
-        const u32 p0 = atomicAdd (&BK.cursors[tid * TJ_CSTRIDE], cnt);
-        const u32 ch = (u32) TJ_CH0 << BK.ch_shift;
-        bucket_claim_ahead_range (BK, tid, p0, cnt, ctr);   // (a run of up to TJ_LOGB records may hold more than one chunk's first record)
-        const u32 j0 = chunk_of_pos (BK, p0), j1 = chunk_of_pos (BK, p0 + cnt - 1);
-        if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (BK, tid, j0, true, ctr); }
-        if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch))) - 8ull * off;
-        if (j1 != j0) {                                   // the run crosses into the next chunk (chunks are longer than a log block: at most once)
-          thr = off + ((j0 + 1u) * ch - p0);
-          cur_j = j0 + 1u; cur_chunk = bucket_chunk_id (BK, tid, j0 + 1u, true, ctr);
-          if (cur_chunk != TJ_NOCHUNK) a2 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch)) - 8ull * thr;
+    if (n) {
+      PLSTAMP (1);
+      lds_barrier ();
+      PLSTAMP (2);
+      // ---- owners: prefix, reservation, where the run lives
+      if (wave < TJ_P / 64) {
+        const uint4 h4 = *reinterpret_cast<const uint4 *> (&L.hist[4 * lane]);
+        const u32 tot = h4.x + h4.y + h4.z + h4.w;
+        const u32 e0 = wave_inclusive_scan (tot) - tot;
+        if ((lane >> 4) == wave) *reinterpret_cast<uint4 *> (&L.offs[4 * lane]) = make_uint4 (e0, e0 + h4.x, e0 + h4.x + h4.y, e0 + h4.x + h4.y + h4.z);
+        const u32 cnt = L.hist[tid], off = L.offs[tid];
+        u64 a1 = 0, a2 = 0;
+        u32 thr = off + cnt;
+        if (cnt) {
+          const u32 p0 = atomicAdd (&BK.cursors[tid * TJ_CSTRIDE], cnt);
+          const u32 ch = (u32) TJ_CH0 << BK.ch_shift;
+          bucket_claim_ahead_range (BK, tid, p0, cnt, ctr);   // (a run of up to TJ_LOGB records may hold more than one chunk's first record)
+          const u32 j0 = chunk_of_pos (BK, p0), j1 = chunk_of_pos (BK, p0 + cnt - 1);
+          if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (BK, tid, j0, true, ctr); }
+          if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch))) - 8ull * off;
+          if (j1 != j0) {                                 // the run crosses into the next chunk (chunks are longer than a log block: at most once)
+            thr = off + ((j0 + 1u) * ch - p0);
+            cur_j = j0 + 1u; cur_chunk = bucket_chunk_id (BK, tid, j0 + 1u, true, ctr);
+            if (cur_chunk != TJ_NOCHUNK) a2 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch)) - 8ull * thr;
+          }
         }
+        reinterpret_cast<uint4 *> (L.gbase)[tid] = make_uint4 ((u32) a1, (u32) (a1 >> 32) | (thr << 16), (u32) a2, (u32) (a2 >> 32));
       }
-      reinterpret_cast<uint4 *> (L.gbase)[tid] = make_uint4 ((u32) a1, (u32) (a1 >> 32) | (thr << 16), (u32) a2, (u32) (a2 >> 32));
-    }
-    lds_barrier ();
-    if (tid < TJ_P) L.hist[tid] = 0;                      // (for the next block; sweep 2 counts in offs)
-    // ---- sweep 2: every record to its sorted slot (offs[bucket] runs from the bucket's first slot to its last)
+      PLSTAMP (3);
+      lds_barrier ();
+      PLSTAMP (4);
+      if (tid < TJ_P) L.hist[tid] = 0;                    // (for the next block; the ranks below count in offs)
+      // ---- every record to its sorted slot (offs[bucket] runs from the bucket's first slot to its last)
 #pragma unroll
-    for (u32 r0 = 0; r0 < RR; r0 += 8) {
-      if (r0 * PL_BLOCK >= n) break;
-      u64 w[8];
-#pragma unroll
-      for (u32 r = 0; r < 8; r++) { const u32 i = tid + (r0 + r) * PL_BLOCK; w[r] = src[i < n ? i : 0u]; }
-#pragma unroll
-      for (u32 r = 0; r < 8; r++) {
-        const u32 i = tid + (r0 + r) * PL_BLOCK;
-        if (i < n) {
-          const u32 bin = bucket_of_rec1 ((u32) w[r], (u32) (w[r] >> 32));
+      for (u32 r = 0; r < RR; r++)
+        if (tid + r * PL_BLOCK < n) {
+          const u32 bin = (pk[r >> 2] >> (8u * (r & 3u))) & 255u;
           const u32 d = atomicAdd (&L.offs[bin], 1u);
           L.rec[d] = w[r];
           L.bin[d] = (unsigned char) bin;
         }
-      }
-    }
-    __builtin_amdgcn_s_waitcnt (0x0F70);                  // vmcnt(0): nothing but the stores below in flight from here on
-    lds_barrier ();
-    // ---- copy-out: sorted slot i -> its place in the bucket's run
+      PLSTAMP (5);
+      lds_barrier ();
+      PLSTAMP (6);
+      // ---- copy-out: sorted slot i -> its place in the bucket's run
 #pragma unroll
-    for (u32 r0 = 0; r0 < RR; r0 += 4) {
-      if (r0 * PL_BLOCK >= n) break;
-      u32 cb[4]; uint4 e[4]; u64 cw[4];
+      for (u32 r0 = 0; r0 < RR; r0 += 4) {
+        if (r0 * PL_BLOCK >= n) break;
+        u32 cb[4]; uint4 e[4]; u64 cw[4];
 #pragma unroll
-      for (u32 h = 0; h < 4; h++) cb[h] = L.bin[tid + (r0 + h) * PL_BLOCK];
+        for (u32 h = 0; h < 4; h++) cb[h] = L.bin[tq + (r0 + h) * PL_BLOCK];
 #pragma unroll
-      for (u32 h = 0; h < 4; h++) { e[h] = reinterpret_cast<const uint4 *> (L.gbase)[cb[h]]; cw[h] = L.rec[tid + (r0 + h) * PL_BLOCK]; }
+        for (u32 h = 0; h < 4; h++) { e[h] = reinterpret_cast<const uint4 *> (L.gbase)[cb[h]]; cw[h] = L.rec[tq + (r0 + h) * PL_BLOCK]; }
 #pragma unroll
-      for (u32 h = 0; h < 4; h++) {
-        const u32 i = tid + (r0 + h) * PL_BLOCK;
-        const u64 a = (i < (e[h].y >> 16)) ? (((u64) (e[h].y & 0xFFFFu) << 32) | e[h].x) : (((u64) e[h].w << 32) | e[h].z);
-        if (i < n && a != 0ull) {
-          typedef __attribute__((address_space(1))) u64 *gwords_t;
-          *(gwords_t) (a + 8ull * i) = cw[h];
+        for (u32 h = 0; h < 4; h++) {
+          const u32 i = tq + (r0 + h) * PL_BLOCK;
+          const u64 a = (i < (e[h].y >> 16)) ? (((u64) (e[h].y & 0xFFFFu) << 32) | e[h].x) : (((u64) e[h].w << 32) | e[h].z);
+          if (i < n && a != 0ull) {
+            typedef __attribute__((address_space(1))) u64 *gwords_t;
+            *(gwords_t) (a + (u64) (8u * i)) = cw[h];
+          }
         }
       }
+      PLSTAMP (7);
+      lds_barrier ();                                     // the sorted buffer is free again
+      PLSTAMP (8);
     }
-    lds_barrier ();                                       // the sorted buffer is free again
+    if (!more) break;
+    {
+      const u64 *__restrict__ src = LG.log + ((u64) bn << TJ_LOGB_SHIFT);
+      nn = LG.count[bn];
+#pragma unroll
+      for (u32 r = 0; r < RR; r++) w[r] = (src + r * PL_BLOCK)[tid];
+    }
+    n = nn; b = bn;
   }
+  PLSTAMP_FLUSH;
 }
 
 template <int W>
@@ -4444,7 +4469,8 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
   LogSpace LG = {nullptr, nullptr, nullptr, 0u};
   const int fgrid_log = (int) std::min<long> (n_ftiles, (long) c->n_cu * FK_LOG_WG_PER_CU);
   if (use_log) {
-    const u64 n_blocks = (bound >> TJ_LOGB_SHIFT) + 2ull * (u64) fgrid_log + 4ull;
+    // (a workgroup with n records has taken at most n / TJ_LOGB + 3 blocks: the one being filled and up to two ahead of it)
+    const u64 n_blocks = (bound >> TJ_LOGB_SHIFT) + 3ull * (u64) fgrid_log + 8ull;
     rc = ensure (c->log, (size_t) (((n_blocks << TJ_LOGB_SHIFT) + 64ull * (u64) fgrid_log) * 8ull), c->stream);
     if (!rc && (size_t) (n_blocks + 2) * 4 > c->logmeta.cap) {
       rc = ensure (c->logmeta, (size_t) (n_blocks + 2) * 4 * 2, c->stream);
@@ -5035,6 +5061,10 @@ extern "C" double tjamd_last_scan_ms (tjamd_counter *c)
   if (hipSetDevice (c->device) != hipSuccess || hipEventSynchronize (c->ev_s1) != hipSuccess || hipEventElapsedTime (&ms, c->ev_s0, c->ev_s1) != hipSuccess) return -1.0;
   return (double) ms;
 }
+
+// 1: one-word records go through the record log and partition_log_kernel (k <= 12, the default); 0: every scan kernel
+// partitions its records itself
+extern "C" int tjamd_counter_uses_log (const tjamd_counter *c) { return (c && c->W == 1 && c->log_mode && c->fast_mode) ? 1 : 0; }
 
 extern "C" double tjamd_last_partition_ms (tjamd_counter *c)
 { // partition_log_kernel behind the last scan launch (k <= 12, record log); 0 when the scan partitioned by itself

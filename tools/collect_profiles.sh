@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/collect_profiles.sh [tag] [bench args...]'   -> gpurun_out/<tag>/*      (tag defaults to r02)
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r03}; shift || true
+TAG=${1:-r04}; shift || true
 # one rank only: with --gpus N > 1 bench.py becomes a launcher that starts its ranks as child processes, and under
 # rocprofv3 (whose preloaded library has initialised the GPU in that parent) such a hop is forbidden on this pool
 for a in "$@"; do case "$prev$a" in --gpus[2-9]*|--gpus=[2-9]*|--gpus1[0-9]*) echo "collect_profiles.sh: profile one rank (no --gpus N > 1)"; exit 2;; esac; prev=$a; done

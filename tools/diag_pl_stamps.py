@@ -21,9 +21,9 @@ for it in range(3):
     c.reset(); c.scan_device(d.data_ptr(), s.size, 3); c.sync()
     L.tjamd_debug_stamps(out, 1)
 v = np.array(list(out), dtype=np.float64)
-names = ["0 loop/count", "1 H: loads+adds", "2 H: barrier", "3 reserve", "4 (after passes)", "5", "6", "7", "8", "9 pass: loads+hash", "10 pass: rank+barrier",
-         "11 pass: prefix+barrier", "12 pass: permute", "13 pass: owners", "14 pass: wait+barrier", "15 pass: copy-out+barrier"]
+names = ["0 loop/count", "1 sweep 1: loads + counts", "2 barrier", "3 owners: prefix, reservation, chunk", "4 barrier", "5 sweep 2: loads + LDS sort", "6 wait + barrier",
+         "7 copy-out", "8 barrier"]
 print("partition ms", c.last_partition_ms(), "ticks total", v[:16].sum())
-for n, x in zip(names, v[:16]):
-    print(f"{n:28s} {x / v[:16].sum() * 100:6.2f} %")
+for n, x in zip(names, v[:9]):
+    print(f"{n:40s} {x / v[:16].sum() * 100:6.2f} %")
 c.close()

@@ -25,6 +25,11 @@ if [ "$MODE" != quick ]; then
     if [ $rc -ne 0 ]; then echo "TESTS FAILED (FAST=$f)"; exit 1; fi
   done
 fi
+if [ "$MODE" != quick ]; then      # the in-kernel partition of rounds 1-3 (k <= 12), still the path of k > 12
+  TATAJUBA_AMD_SINK=fused timeout -k 10 500 python -m pytest tests -m gpu -x -q > $O/tests_fused.log 2>&1; rc=$?
+  echo "SINK=fused: $(tail -1 $O/tests_fused.log)"
+  if [ $rc -ne 0 ]; then echo "TESTS FAILED (SINK=fused)"; exit 1; fi
+fi
 if [ "$MODE" = full ]; then
   bash tools/exp_valu.sh > $O/valu.log 2>&1; tail -4 $O/valu.log
 fi

@@ -2,9 +2,9 @@
 usage: install_profiles.py [tag]      (tag defaults to r02)"""
 import collections, csv, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G, P = os.path.join(R, "gpurun_out", TAG), os.path.join(R, "profiles")
-HOT = ("scan_fast", "scan_bins", "aggregate", "bin_sort_index")
+HOT = ("scan_fast", "scan_bins", "partition_log", "aggregate", "bin_sort_index")
 shutil.copy(os.path.join(G, "kt", "kt_kernel_stats.csv"), os.path.join(P, TAG + "_kernel_stats.csv"))
 bench = None
 for src, dst in (("bench_under_rocprof.json", TAG + "_bench_under_rocprof.json"), ("bench_plain.json", TAG + "_bench.json")):

@@ -24,10 +24,12 @@ write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"_note": __doc__.split("\n\n")[1].replace("\n", " ")}
 for k in sorted(set(fetch) | set(write)):
     short = k.split("(")[0].replace("void ", "")
-    if not any(s in short for s in ("scan_fast", "scan_bins", "aggregate", "radix_scatter")):
+    if not any(s in short for s in ("scan_fast", "scan_bins", "aggregate", "radix_scatter", "partition_log")):
         continue
     f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
-    corr = 2.0 if ("scan_bins" in short or "scan_fast" in short) else 1.0
+    # (partition_log_kernel reads its records 8 B per lane, coalesced: FETCH_SIZE reports half of those bytes as well -- its 0.25 M KiB
+    # for a log of 0.48 GB -- so the same correction applies; its writes, in runs of 32 records, are counted as written)
+    corr = 2.0 if ("scan_bins" in short or "scan_fast" in short or "partition_log" in short) else 1.0
     out[short] = {"launches_averaged": nf.get(k, 0), "FETCH_SIZE_KiB_raw": f_kib, "WRITE_SIZE_KiB_raw": w_kib,
                   "fetch_correction": corr, "hbm_read_bytes": f_kib * 1024 * corr, "hbm_write_bytes": w_kib * 1024,
                   "hbm_bytes": f_kib * 1024 * corr + w_kib * 1024, "calibrated": corr == 2.0}
