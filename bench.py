@@ -106,11 +106,41 @@ def rehearse(args):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
+    mine = {"allgather_ms": [], "merge_ms": [], "bytes": [], "collectives": [], "scan_ms": None, "rccl_ranks": None}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)             # (the same plumbing the real run reports its exchange with)
     if rank == 0:
         print(json.dumps({"rehearsal": True, "n_gpus": world, "max_over_ranks": float(t.item()), "value": None,
-                          "config": {"workload": workload_label(args)}}))
+                          "config": {"workload": workload_label(args), "rccl_ranks": None},
+                          "stages": {"exchange": exchange_report(per_rank)}}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def exchange_report(per_rank):
+    """What a multi-GPU line says about the histogram exchange (all-gatherv of the kept records + merge), from what
+    every rank measured: per_rank[r] = {"allgather_ms": [...], "merge_ms": [...], "bytes": [...], "collectives": [...],
+    "scan_ms": mean scan ms or None, "rccl_ranks": ncclCommCount or None}.  Times are device times (HIP events inside the
+    library, on the exchange's stream); "max_over_ranks" is the mean of the slowest rank."""
+    def stat(key):
+        means = [float(np.mean(p[key])) for p in per_rank if p.get(key)]
+        return {"mean": float(np.mean(means)), "max_over_ranks": float(np.max(means))} if means else None
+    n_ex = [len(p.get("allgather_ms") or []) for p in per_rank]
+    colls = [x for p in per_rank for x in (p.get("collectives") or [])]
+    nbytes = [x for p in per_rank for x in (p.get("bytes") or [])]
+    scans = [p["scan_ms"] for p in per_rank if p.get("scan_ms") is not None]
+    ranks = sorted({p["rccl_ranks"] for p in per_rank if p.get("rccl_ranks") is not None})
+    return {"measured": bool(colls), "exchanges_per_rank": int(min(n_ex)) if n_ex else 0,
+            "allgather_ms": stat("allgather_ms"), "merge_ms": stat("merge_ms"),
+            "bytes_gathered_per_rank_and_exchange": float(np.mean(nbytes)) if nbytes else None,
+            "collectives_per_exchange": float(np.mean(colls)) if colls else None,
+            "rccl_ranks_reported": ranks if ranks else None,
+            "scan_ms_per_rank": {"min": float(np.min(scans)), "max": float(np.max(scans))} if scans else None,
+            "note": "tjamd_allgather_histograms (one ncclAllGather of max-padded blocks per settled exchange, pack + unpack kernels) and tjamd_merge_samples "
+                    "on the side stream, under the next sample's scan; device times from HIP events inside the library; never run on more than one GPU "
+                    "before the driver's 8-GPU node (the pool's boxes have one)"}
 
 
 def workload_label(args):
@@ -272,10 +302,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # The job's control plane (rendezvous, barrier, the max over ranks of one number) goes over gloo: the data path -- the
+        # all-gatherv of the histograms -- is the C library's own RCCL communicator (tjamd_comm_*), and a second NCCL
+        # communicator inside torch for two barriers would only take device memory and channels away from it.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     k, m, L = args.kmer, args.min_tract, args.read_len
     # one sample per rank: same genome, per-sample tract-length variants and read seeds (SURVEY 8d config 4 recipe)
@@ -314,6 +344,7 @@ def main():
     # The exchange is the C library's (tjamd_allgather_histograms: ncclAllGather over RCCL, on the side stream) whenever the
     # ranks have a GPU each; the gloo rehearsal on a one-GPU box keeps the torch.distributed plumbing of tatajuba_amd/dist.py.
     comm = None
+    ex_stats = {"allgather_ms": [], "merge_ms": [], "bytes": [], "collectives": []}     # per exchange of this rank
     union_buf = {"keys": None, "mat": None, "cap": 0}
     if world > 1 and backend == "nccl":
         ident = [tj.Comm.unique_id() if rank == 0 else None]
@@ -336,6 +367,10 @@ def main():
             if nu < 0:
                 raise RuntimeError(tj.lib().tjamd_last_error().decode())
             gathered = (union_buf["keys"][: nu * 24], union_buf["mat"][:nu])
+            le = comm.last_exchange()
+            if le is not None:
+                ex_stats["allgather_ms"].append(le[0]); ex_stats["bytes"].append(le[1]); ex_stats["collectives"].append(le[2])
+            ex_stats["merge_ms"].append(merger.last_merge_ms())
             return
         from tatajuba_amd.dist import all_gather_histograms, merge_histograms_device
         with torch.cuda.stream(side):
@@ -414,6 +449,8 @@ def main():
     drain()
     fence()
     times.clear()
+    for v in ex_stats.values():
+        v.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -423,7 +460,7 @@ def main():
     assert len(times) == args.steps
     scan_ms, fin_ms, part_ms = [t[0] for t in times], [t[1] for t in times], [t[2] for t in times]
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -489,6 +526,13 @@ def main():
                             "note": "stream resident in HBM (the throughput `value` is quoted on)"},
                    "finalise": {"ms": fin_avg, "algorithmic_GBps": fin_gbs, "frac_of_hbm_peak": fin_gbs / HBM_PEAK_GBS}},
     }
+    if world > 1:
+        mine = dict(ex_stats, scan_ms=scan_avg, rccl_ranks=(comm.count if comm is not None else None))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        out["stages"]["exchange"] = exchange_report(per_rank)
+        out["config"]["rccl_ranks"] = comm.count if comm is not None else None
+        out["config"]["control_plane"] = "torch.distributed over gloo (rendezvous, barrier, max over ranks); data path: the library's RCCL communicator"
     if uses_log:
         # k <= 12: the scan kernel appends its records to a linear log, partition_log_kernel distributes the log over the hash
         # buckets (its algorithmic bytes: every record read once and written once)

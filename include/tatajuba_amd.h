@@ -165,6 +165,11 @@ void tjamd_comm_destroy (tjamd_comm *comm);
 int  tjamd_comm_set_stream (tjamd_comm *comm, void *hip_stream);
 int  tjamd_comm_rank (const tjamd_comm *comm);
 int  tjamd_comm_world (const tjamd_comm *comm);
+int  tjamd_comm_count (const tjamd_comm *comm);            /* ranks RCCL itself reports for the communicator (ncclCommCount); -1 on failure */
+/* the last exchange on this communicator: device milliseconds from the first pack to the last unpack (HIP events on the
+ * exchange's stream), bytes the data collective delivered to this rank, collectives it took; any pointer may be NULL;
+ * non-zero before the first exchange */
+int  tjamd_comm_last_exchange (const tjamd_comm *comm, double *ms, long *bytes, long *collectives);
 long tjamd_comm_collectives (const tjamd_comm *comm);    /* RCCL calls issued so far (diagnostic: one per exchange once the block size has settled) */
 long tjamd_allgather_histograms (tjamd_counter *c, tjamd_comm *comm, const void **d_records, long *counts);
 
@@ -205,7 +210,8 @@ void tjamd_thread_cleanup (void);
 double tjamd_last_scan_ms (tjamd_counter *c);       /* scan kernel(s) of the last tjamd_scan_* call */
 int    tjamd_counter_uses_log (const tjamd_counter *c);  /* 1: k <= 12 and the scan writes a record log that partition_log_kernel distributes (default); 0: the scan kernels partition by themselves (k > 12, or TATAJUBA_AMD_SINK=fused) */
 double tjamd_last_partition_ms (tjamd_counter *c);  /* partition_log_kernel behind the last scan launch (k <= 12); 0 if the scan kernel partitioned by itself */
-double tjamd_last_finalise_ms (tjamd_counter *c);   /* whole device finalise of the last tjamd_finalise call */
+double tjamd_last_finalise_ms (tjamd_counter *c);
+double tjamd_last_merge_ms (tjamd_counter *c);      /* kernels of the last tjamd_merge_samples on this counter */   /* whole device finalise of the last tjamd_finalise call */
 long   tjamd_last_scan_launches (tjamd_counter *c);
 /* finalises of this counter whose device-side sizing of the ordering step had read a stale kept count (checked against the
  * count at the next kernel boundary and repaired; expected to stay 0) */

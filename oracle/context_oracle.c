@@ -11,8 +11,14 @@
  * PARITY UNPINNED for two pieces whose source is absent from /root/reference (biomcmc-lib, an empty submodule, version
  * not recorded anywhere in the tree):
  *   - biomcmc_levenshtein_distance (s1, n1, s2, n2, 1, 1, true): restated as the plain global edit distance with
- *     substitution cost 1 and insertion / deletion cost 1 (the two cost arguments); the meaning of the last argument
- *     cannot be checked here.
+ *     substitution cost 1 and insertion / deletion cost 1 (the two cost arguments).  The last argument cannot be checked
+ *     here.  Two readings: (a) "skip the borders" = strip the common prefix and suffix of the two strings before the
+ *     dynamic programme -- the usual shortcut, which leaves the global distance unchanged (then this restatement is exact);
+ *     (b) free end gaps (a semi-global distance), under which a one-base shift of a name costs 1 instead of 2 and the default
+ *     `levenshtein_distance = max_distance_per_flank + 1` would merge contexts that this restatement keeps apart.  The
+ *     restatement follows (a), which is what the function's name and its two cost arguments suggest;
+ *     tests/test_cabi.py::test_edit_distance_readings_differ_on_a_shifted_name shows a pair on which (a) and (b) differ, so
+ *     that whoever holds biomcmc-lib can settle it with one call.  Product (device, host) and oracle share reading (a).
  *   - new_empfreq_from_int_weighted (lengths, n, counts): restated as "distinct values with their summed weights, highest
  *     sum first" (context_histogram.h:42: "h.idx = tract length; h.freq = count"; src/context_histogram.c:282: "histogram,
  *     from high to low count"); the order among equal sums is not stated in the reference: here the larger value first.

@@ -90,7 +90,7 @@ EXPORTS = [
     "tjamd_download_raw", "tjamd_undefined_runs", "tjamd_upload_raw", "tjamd_finalise", "tjamd_finalise_begin", "tjamd_finalise_end", "tjamd_kept_count",
     "tjamd_n_idx", "tjamd_coverage", "tjamd_download_kept", "tjamd_download_idx", "tjamd_kept_device_ptr",
     "tjamd_merge_samples", "tjamd_gather_histograms", "tjamd_peer_access_report", "tjamd_comm_unique_id", "tjamd_comm_create", "tjamd_comm_destroy",
-    "tjamd_comm_set_stream", "tjamd_comm_rank", "tjamd_comm_world", "tjamd_comm_collectives", "tjamd_allgather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_context_histograms", "tjamd_scan_windows", "tjamd_thread_cleanup", "tjamd_last_scan_ms", "tjamd_last_partition_ms", "tjamd_counter_uses_log", "tjamd_last_finalise_ms", "tjamd_last_scan_launches", "tjamd_plan_mismatches",
+    "tjamd_comm_set_stream", "tjamd_comm_rank", "tjamd_comm_world", "tjamd_comm_collectives", "tjamd_comm_count", "tjamd_comm_last_exchange", "tjamd_last_merge_ms", "tjamd_allgather_histograms", "tjamd_tract_ids", "tjamd_group_contexts", "tjamd_context_histograms", "tjamd_scan_windows", "tjamd_thread_cleanup", "tjamd_last_scan_ms", "tjamd_last_partition_ms", "tjamd_counter_uses_log", "tjamd_last_finalise_ms", "tjamd_last_scan_launches", "tjamd_plan_mismatches",
     "tjamd_synth_stream", "tjamd_read_file_stream",
     # include/tatajuba_context.h
     "new_genomic_context_list", "del_genomic_context_list", "del_context_histogram",
@@ -335,6 +335,23 @@ class Comm:
     def collectives(self):
         return lib().tjamd_comm_collectives(self._h)
 
+    @property
+    def count(self):
+        """ranks RCCL reports for the communicator (ncclCommCount)"""
+        lib().tjamd_comm_count.restype = C.c_int
+        lib().tjamd_comm_count.argtypes = [C.c_void_p]
+        return int(lib().tjamd_comm_count(self._h))
+
+    def last_exchange(self):
+        """(device ms, bytes delivered to this rank, collectives) of the last allgather; None before the first"""
+        f = lib().tjamd_comm_last_exchange
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        ms, nb, nc = C.c_double(), C.c_long(), C.c_long()
+        if f(self._h, C.byref(ms), C.byref(nb), C.byref(nc)) != 0:
+            return None
+        return ms.value, nb.value, nc.value
+
     def close(self):
         if getattr(self, "_h", None):
             lib().tjamd_comm_destroy(self._h)
@@ -487,6 +504,11 @@ class Counter:
 
     def last_partition_ms(self):
         return lib().tjamd_last_partition_ms(self._h)
+
+    def last_merge_ms(self):
+        lib().tjamd_last_merge_ms.restype = C.c_double
+        lib().tjamd_last_merge_ms.argtypes = [C.c_void_p]
+        return lib().tjamd_last_merge_ms(self._h)
 
     def uses_log(self):
         lib().tjamd_counter_uses_log.restype = C.c_int

@@ -4050,6 +4050,7 @@ struct tjamd_counter
   bool log_mode = true;       // k <= 12: the fast kernel writes a log and partition_log_kernel fills the buckets (TATAJUBA_AMD_SINK=fused: the kernel partitions by itself)
   bool log_next_clean[2] = {false, false};
   hipEvent_t ev_p1 = nullptr; // after the partition kernel of the last scan call
+  hipEvent_t ev_m0 = nullptr, ev_m1 = nullptr; bool merge_timed = false;   // around the kernels of the last tjamd_merge_samples
   bool part_timed = false;
   int fast_mode = 1;          // 1: scan_fast_kernel + the generic kernel on what it leaves; 0: generic kernel only; 2: fast kernel leaves everything (tests)
   u32 pool_chunks = 0, maxj = 0;
@@ -4143,6 +4144,7 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   HIPCHK_NULL (hipEventCreate (&c->ev_s0)); HIPCHK_NULL (hipEventCreate (&c->ev_s1));
   HIPCHK_NULL (hipEventCreate (&c->ev_f0)); HIPCHK_NULL (hipEventCreate (&c->ev_f1));
   HIPCHK_NULL (hipEventCreate (&c->ev_p1));
+  HIPCHK_NULL (hipEventCreate (&c->ev_m0)); HIPCHK_NULL (hipEventCreate (&c->ev_m1));
   HIPCHK_NULL (hipEventCreateWithFlags (&c->ev_done, hipEventDisableTiming));
   HIPCHK_NULL (hipEventCreateWithFlags (&c->ev_agg, hipEventDisableTiming));
   HIPCHK_NULL (hipStreamSynchronize (c->stream));
@@ -4166,6 +4168,8 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   if (c->ev_s0) (void) hipEventDestroy (c->ev_s0);
   if (c->ev_s1) (void) hipEventDestroy (c->ev_s1);
   if (c->ev_p1) (void) hipEventDestroy (c->ev_p1);
+  if (c->ev_m0) (void) hipEventDestroy (c->ev_m0);
+  if (c->ev_m1) (void) hipEventDestroy (c->ev_m1);
   if (c->ev_f0) (void) hipEventDestroy (c->ev_f0);
   if (c->ev_f1) (void) hipEventDestroy (c->ev_f1);
   if (c->ev_done) (void) hipEventDestroy (c->ev_done);
@@ -5062,6 +5066,14 @@ extern "C" double tjamd_last_scan_ms (tjamd_counter *c)
   return (double) ms;
 }
 
+extern "C" double tjamd_last_merge_ms (tjamd_counter *c)
+{ // the kernels of the last tjamd_merge_samples on this counter (bin path), HIP events on its stream
+  if (!c || !c->merge_timed) return -1.0;
+  float ms = 0.f;
+  if (hipSetDevice (c->device) != hipSuccess || hipEventSynchronize (c->ev_m1) != hipSuccess || hipEventElapsedTime (&ms, c->ev_m0, c->ev_m1) != hipSuccess) return -1.0;
+  return (double) ms;
+}
+
 // 1: one-word records go through the record log and partition_log_kernel (k <= 12, the default); 0: every scan kernel
 // partitions its records itself
 extern "C" int tjamd_counter_uses_log (const tjamd_counter *c) { return (c && c->W == 1 && c->log_mode && c->fast_mode) ? 1 : 0; }
@@ -5557,6 +5569,7 @@ extern "C" long tjamd_merge_samples (tjamd_counter *c, const void *d_records, co
   u32 *tpos = (u32 *) c->headpos.p, *ttot = (u32 *) c->outpos.p;
   if (!c->bins_zeroed && hipMemsetAsync (bins, 0, (size_t) BS_MAXBINS * 4, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "memset failed");
   c->bins_zeroed = false;
+  (void) hipEventRecord (c->ev_m0, c->stream);
   hipLaunchKernelGGL (bin_count_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const u64 *) d_records, n, c->k, nbits, bins, (uint4 *) nullptr, 0l, 1);
   hipLaunchKernelGGL (bin_scan_kernel, dim3 (1), dim3 (1024), 0, c->stream, bins, nbins, binstart,
                       c->bin_rank_max < (u32) BS_RANK_MAX ? c->bin_rank_max : (u32) MG_RANK_MAX, c->d_fin);   // (test hook: see TATAJUBA_AMD_BIN_MAX)
@@ -5569,6 +5582,8 @@ extern "C" long tjamd_merge_samples (tjamd_counter *c, const void *d_records, co
                       (const u32 *) binout, nbins, (const FinCounts *) c->d_fin, (const u32 *) tpos, (const u32 *) ttot, n_samples,
                       (u64 *) d_out_keys, (int *) d_out_counts, capacity);
   if (hipGetLastError () != hipSuccess) return -set_err (TJAMD_ERR_HIP, "merge launch failed");
+  (void) hipEventRecord (c->ev_m1, c->stream);
+  c->merge_timed = true;
   if (hipMemcpyAsync (c->h_fin, c->d_fin, sizeof (FinCounts), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "merge failed: %s", hipGetErrorString (hipGetLastError ()));
   if (c->h_fin->sort_fallback) return merge_samples_radix (c, d_records, n, n_samples, d_out_keys, d_out_counts, capacity);
@@ -5629,6 +5644,10 @@ struct tjamd_comm
   DevBuf send, recv, out, dcounts;
   long *h_counts = nullptr;                             // pinned, world entries
   long exchanges = 0, collectives = 0;
+  // the last exchange, for whoever reports on it (bench.py): device time from the first pack to the last unpack (HIP events on
+  // the exchange's stream), bytes received, collectives it took (1 when the block size was settled, 2 or more otherwise)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = -1.0; long last_bytes = 0, last_collectives = 0;
 };
 
 #define NCCLCHK(call, ret) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
@@ -5655,8 +5674,9 @@ extern "C" tjamd_comm *tjamd_comm_create (tjamd_counter *c, const void *id_bytes
   memcpy (&id, id_bytes, sizeof id);
   ncclResult_t r = ncclCommInitRank (&m->comm, world, id, rank);
   if (r != ncclSuccess) { set_err (TJAMD_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString (r)); delete m; return NULL; }
-  if (hipHostMalloc ((void **) &m->h_counts, (size_t) world * sizeof (long), hipHostMallocDefault) != hipSuccess) {
-    set_err (TJAMD_ERR_HIP, "hipHostMalloc failed"); (void) ncclCommDestroy (m->comm); delete m; return NULL;
+  if (hipHostMalloc ((void **) &m->h_counts, (size_t) world * sizeof (long), hipHostMallocDefault) != hipSuccess ||
+      hipEventCreate (&m->ev0) != hipSuccess || hipEventCreate (&m->ev1) != hipSuccess) {
+    set_err (TJAMD_ERR_HIP, "hipHostMalloc / hipEventCreate failed"); (void) ncclCommDestroy (m->comm); delete m; return NULL;
   }
   return m;
 }
@@ -5668,6 +5688,8 @@ extern "C" void tjamd_comm_destroy (tjamd_comm *m)
   if (m->comm) (void) ncclCommDestroy (m->comm);
   release (m->send); release (m->recv); release (m->out); release (m->dcounts);
   if (m->h_counts) (void) hipHostFree (m->h_counts);
+  if (m->ev0) (void) hipEventDestroy (m->ev0);
+  if (m->ev1) (void) hipEventDestroy (m->ev1);
   delete m;
 }
 
@@ -5679,6 +5701,23 @@ extern "C" int tjamd_comm_set_stream (tjamd_comm *m, void *hip_stream)
 }
 extern "C" int tjamd_comm_rank (const tjamd_comm *m) { return m ? m->rank : -1; }
 extern "C" int tjamd_comm_world (const tjamd_comm *m) { return m ? m->world : -1; }
+// the number of ranks RCCL itself says the communicator has (ncclCommCount), not the argument tjamd_comm_create was given
+extern "C" int tjamd_comm_count (const tjamd_comm *m)
+{
+  int n = -1;
+  if (!m || !m->comm || ncclCommCount (m->comm, &n) != ncclSuccess) return -1;
+  return n;
+}
+// the last exchange on this communicator: device milliseconds (pack, collective(s), unpack), bytes the data collective
+// delivered to this rank, collectives it took.  Any pointer may be NULL.  Returns 0, or non-zero before the first exchange.
+extern "C" int tjamd_comm_last_exchange (const tjamd_comm *m, double *ms, long *bytes, long *collectives)
+{
+  if (!m || m->exchanges == 0 || m->last_collectives == 0) return 1;
+  if (ms) *ms = m->last_ms;
+  if (bytes) *bytes = m->last_bytes;
+  if (collectives) *collectives = m->last_collectives;
+  return 0;
+}
 extern "C" long tjamd_comm_collectives (const tjamd_comm *m) { return m ? m->collectives : -1; }
 
 #define GX_HEADER 16                                    // bytes in front of a block's records: the record count, then padding
@@ -5714,22 +5753,28 @@ extern "C" long tjamd_allgather_histograms (tjamd_counter *c, tjamd_comm *m, con
   if (c->status < 0) return -set_err (TJAMD_ERR_STATE, "tjamd_allgather_histograms needs a finalised counter");
   if (c->device != m->device) return -set_err (TJAMD_ERR_ARG, "the communicator was made for device %d, the counter lives on %d", m->device, c->device);
   if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
+  if (!m->comm) return -set_err (TJAMD_ERR_STATE, "the communicator was aborted after a failed exchange");
   const int world = m->world;
   const long n_mine = c->n_kept;
+  // A rank that gives up between two collectives would leave its peers waiting in theirs for ever: every failure from
+  // here on aborts the communicator (ncclCommAbort: the peers' pending and later calls fail instead of hanging).
+  auto give_up = [&] (int code) -> long { if (m->comm) { (void) ncclCommAbort (m->comm); m->comm = nullptr; } return -(long) code; };
   // (a stream of the communicator's own: the exchange of a finalised sample runs beside the scan of the next one; the
   // caller has seen this counter's finalise end -- tjamd_finalise / tjamd_finalise_end -- so its kept records are complete)
   const hipStream_t st = m->stream ? m->stream : c->stream;
   int rc = ensure (m->dcounts, (size_t) (world + 1) * sizeof (long), st);
-  if (rc) return -rc;
+  if (rc) return give_up (rc);
   long *d_counts = (long *) m->dcounts.p;
   m->exchanges++;
+  const long collectives_before = m->collectives;
+  (void) hipEventRecord (m->ev0, st);
   for (int attempt = 0; attempt < 3; attempt++) {
     if (m->cap == 0) {                                  // block size not agreed (first exchange, or the last one overflowed): the counts first
-      if (hipMemcpyAsync (d_counts + world, &n_mine, sizeof (long), hipMemcpyHostToDevice, st) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+      if (hipMemcpyAsync (d_counts + world, &n_mine, sizeof (long), hipMemcpyHostToDevice, st) != hipSuccess) return give_up (set_err (TJAMD_ERR_HIP, "copy failed"));
       NCCLCHK (ncclAllGather (d_counts + world, d_counts, sizeof (long), ncclChar, m->comm, st), -TJAMD_ERR_HIP);
       m->collectives++;
       if (hipMemcpyAsync (m->h_counts, d_counts, (size_t) world * sizeof (long), hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize (st) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "exchange of the counts failed: %s", hipGetErrorString (hipGetLastError ()));
+          hipStreamSynchronize (st) != hipSuccess) return give_up (set_err (TJAMD_ERR_HIP, "exchange of the counts failed: %s", hipGetErrorString (hipGetLastError ())));
       long mx = 0;
       for (int r = 0; r < world; r++) mx = std::max (mx, m->h_counts[r]);
       m->cap = gx_block_cap (mx);
@@ -5738,21 +5783,28 @@ extern "C" long tjamd_allgather_histograms (tjamd_counter *c, tjamd_comm *m, con
     rc = ensure (m->send, (size_t) block_words * 8, st);
     if (!rc) rc = ensure (m->recv, (size_t) block_words * 8 * (size_t) world, st);
     if (!rc) rc = ensure (m->out, (size_t) std::max<long> (cap * world, 1) * 24, st);
-    if (rc) return -rc;
+    if (rc) return give_up (rc);
     hipLaunchKernelGGL (gx_pack_kernel, dim3 (grid_for (3 * std::min (n_mine, cap) + 1)), dim3 (256), 0, st, (const u64 *) c->kept.p, n_mine, cap, (u64 *) m->send.p);
     NCCLCHK (ncclAllGather (m->send.p, m->recv.p, (size_t) block_words * 8, ncclChar, m->comm, st), -TJAMD_ERR_HIP);
     m->collectives++;
     hipLaunchKernelGGL (gx_unpack_kernel, dim3 (grid_for (3 * cap + 1), (unsigned) std::min (world, 64)), dim3 (256), 0, st,
                         (const u64 *) m->recv.p, block_words, world, cap, (u64 *) m->out.p, d_counts);
-    if (hipGetLastError () != hipSuccess) return -set_err (TJAMD_ERR_HIP, "exchange launch failed");
+    if (hipGetLastError () != hipSuccess) return give_up (set_err (TJAMD_ERR_HIP, "exchange launch failed"));
+    (void) hipEventRecord (m->ev1, st);
     if (hipMemcpyAsync (m->h_counts, d_counts, (size_t) world * sizeof (long), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize (st) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "exchange failed: %s", hipGetErrorString (hipGetLastError ()));
+        hipStreamSynchronize (st) != hipSuccess) return give_up (set_err (TJAMD_ERR_HIP, "exchange failed: %s", hipGetErrorString (hipGetLastError ())));
     long mx = 0, total = 0;
     for (int r = 0; r < world; r++) { mx = std::max (mx, m->h_counts[r]); total += m->h_counts[r]; }
     if (mx > cap) { m->cap = 0; continue; }             // (every rank sees the same counts and takes the same turn)
     m->cap = gx_block_cap (mx);
     for (int r = 0; r < world; r++) counts[r] = m->h_counts[r];
     *d_records = m->out.p;
+    {
+      float ms = 0.f;
+      m->last_ms = hipEventElapsedTime (&ms, m->ev0, m->ev1) == hipSuccess ? (double) ms : -1.0;
+      m->last_bytes = block_words * 8 * (long) world;     // (what the data collective moved into this rank: every rank's max-padded block)
+      m->last_collectives = m->collectives - collectives_before;
+    }
     return total;
   }
   return -set_err (TJAMD_ERR_STATE, "the exchange did not settle on a block size");

@@ -215,13 +215,19 @@ static int tj_files_in_flight;                          /* new_or_append_hopo_co
  * caller runs one thread per sample, src/genome_set.c:66-68: eight samples at once get an eighth each, one sample alone
  * gets them all), at most TJF_MAX_THREADS.  TATAJUBA_AMD_FEEDER_THREADS overrides. */
 static int
-tj_feeder_threads (void)
+tj_feeder_threads (const tatajuba_options_t *opt)
 {
   const char *e = getenv ("TATAJUBA_AMD_FEEDER_THREADS");
   long n;
   if (e) n = atol (e);
   else {
-    long active = __atomic_load_n (&tj_files_in_flight, __ATOMIC_RELAXED);
+    /* The files being read now are a lower bound only: the reference's caller starts its per-sample threads together, and
+     * the first file to get here would see itself alone and take the whole budget, the second half of it, ...  What the
+     * caller says it will run at once -- min (n_samples, n_threads), the clipping of src/main.c:176-181 -- is the share
+     * to plan for from the first file on. */
+    long active = __atomic_load_n (&tj_files_in_flight, __ATOMIC_RELAXED), planned = 1;
+    if (opt && opt->n_samples > 0 && opt->n_threads > 0) planned = opt->n_samples < opt->n_threads ? opt->n_samples : opt->n_threads;
+    if (active < planned) active = planned;
     if (active < 1) active = 1;
     n = tj_cpu_budget () / active;
   }
@@ -260,7 +266,7 @@ new_or_append_hopo_counter_from_file (hopo_counter hc, const char *filename, tat
     struct stat st;
     int threads;
     (void) __atomic_add_fetch (&tj_files_in_flight, 1, __ATOMIC_RELAXED);
-    threads = tj_feeder_threads ();
+    threads = tj_feeder_threads (&opt);
     const int plain = threads > 1 ? tjf_is_plain_file (filename) : -1;
     if (plain >= 0 && stat (filename, &st) == 0 && st.st_size >= (plain ? TJ_FEEDER_MIN_BYTES : TJ_FEEDER_MIN_GZ_BYTES)) {
       tj_gpu_sink g;
@@ -431,15 +437,21 @@ static __thread int tj_scratch_next;                    /* the slot that is recy
 static pthread_key_t tj_scratch_key;                    /* its destructor releases a thread's contexts when the thread ends */
 static pthread_once_t tj_scratch_once = PTHREAD_ONCE_INIT;
 
+static int tj_process_exiting;                          /* set by an atexit handler: the HIP runtime may be gone by the time a late thread ends */
+static void tj_mark_exit (void) { __atomic_store_n (&tj_process_exiting, 1, __ATOMIC_RELAXED); }
+
 static void
 tj_scratch_release (void *slots)
 {
   tj_scratch_slot *sl = (tj_scratch_slot *) slots;
   int i;
   if (!sl) return;
+  /* a thread that ends while the process is being taken down: the runtime's own destructors may have run -- leave the
+   * contexts to the operating system rather than call into it */
+  if (__atomic_load_n (&tj_process_exiting, __ATOMIC_RELAXED)) return;
   for (i = 0; i < TJ_SCRATCH_SLOTS; i++) if (sl[i].dev) { tjamd_counter_destroy (sl[i].dev); sl[i].dev = NULL; sl[i].k = 0; }
 }
-static void tj_scratch_make_key (void) { (void) pthread_key_create (&tj_scratch_key, tj_scratch_release); }
+static void tj_scratch_make_key (void) { (void) pthread_key_create (&tj_scratch_key, tj_scratch_release); (void) atexit (tj_mark_exit); }
 
 /* release the calling thread's shared scan contexts now (a thread pool that outlives its work; the main thread before
  * exit).  They are released by themselves when a thread ends. */

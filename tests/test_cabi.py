@@ -595,3 +595,32 @@ def test_rccl_exchange_entry_points_check_their_arguments_without_a_gpu():
     L.tjamd_comm_destroy(None)
     buf = C.create_string_buffer(64)
     assert L.tjamd_peer_access_report(buf, 64) == 0 and buf.value == b""
+
+
+def test_edit_distance_readings_differ_on_a_shifted_name():
+    """UNPINNED piece, made explicit: biomcmc_levenshtein_distance (.., 1, 1, true) is absent from the reference tree.  The
+    restatement (oracle, device, host alike) is the global unit-cost distance -- reading (a) of oracle/context_oracle.c's
+    header: the flag strips common borders, which changes nothing.  Under reading (b), free end gaps, a name whose right
+    flank is shifted by one base would cost 1 instead of 2; this pair is where the two readings part, for whoever holds
+    biomcmc-lib to settle with one call."""
+    a, b = "ACGTACGTAC.A.TTGACCATGG", "ACGTACGTAC.A.TGACCATGGA"       # right flank shifted left by one base
+    assert orc.levenshtein(a, b) == 2                                 # global: one deletion + one insertion
+
+    def free_end_gaps(x, y):                                          # reading (b), for contrast only: never used by the product
+        prev = [0] * (len(y) + 1)
+        for i in range(1, len(x) + 1):
+            cur = [0] + [0] * len(y)
+            for j in range(1, len(y) + 1):
+                cur[j] = min(prev[j - 1] + (x[i - 1] != y[j - 1]), prev[j] + 1, cur[j - 1] + 1)
+            prev = cur
+        return min(prev)
+    assert free_end_gaps(a, b) < orc.levenshtein(a, b)
+    # the host function a caller links (include/tatajuba_context.h) follows the same reading as the oracle
+    import ctypes as C
+    L = tj.lib()
+    from tatajuba_amd.capi import ContextHistogramStruct
+    ch = ContextHistogramStruct()
+    ch.name = a.encode()
+    L.indel_distance_between_context_histogram_and_hopo_context.restype = C.c_int
+    L.indel_distance_between_context_histogram_and_hopo_context.argtypes = [C.c_void_p, C.c_char_p]
+    assert L.indel_distance_between_context_histogram_and_hopo_context(C.byref(ch), b.encode()) == 2

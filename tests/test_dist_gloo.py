@@ -104,6 +104,11 @@ def test_bench_launches_its_own_ranks():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["max_over_ranks"] == 2.0
     assert "configs[3]" in d["config"]["workload"]                          # the label follows the arguments
+    # a multi-GPU line describes its exchange (what the driver's 8-GPU run will carry; nothing is measured in a rehearsal)
+    ex = d["stages"]["exchange"]
+    assert set(ex) >= {"measured", "exchanges_per_rank", "allgather_ms", "merge_ms", "bytes_gathered_per_rank_and_exchange",
+                       "collectives_per_exchange", "rccl_ranks_reported", "scan_ms_per_rank"} and ex["measured"] is False
+    assert "rccl_ranks" in d["config"]
     r = subprocess.run([sys.executable, bench, "--rehearse", "--kmer", "13"], env=env, stdout=subprocess.PIPE, timeout=300)
     assert "custom workload" in json.loads(r.stdout.decode().splitlines()[-1])["config"]["workload"]
 

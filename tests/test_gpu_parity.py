@@ -1215,6 +1215,16 @@ def test_rccl_allgather_of_one_rank_and_block_size_protocol():
     comm = L.tjamd_comm_create(small._h, ident, 0, 1)
     assert comm, L.tjamd_last_error()
     assert L.tjamd_comm_rank(comm) == 0 and L.tjamd_comm_world(comm) == 1
+    L.tjamd_comm_count.restype = C.c_int; L.tjamd_comm_count.argtypes = [C.c_void_p]
+    assert L.tjamd_comm_count(comm) == 1                       # what RCCL itself says (ncclCommCount)
+    L.tjamd_comm_last_exchange.restype = C.c_int
+    L.tjamd_comm_last_exchange.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    ms, nb, nc = C.c_double(), C.c_long(), C.c_long()
+    assert L.tjamd_comm_last_exchange(comm, C.byref(ms), C.byref(nb), C.byref(nc)) != 0      # nothing exchanged yet
+
+    def last():
+        assert L.tjamd_comm_last_exchange(comm, C.byref(ms), C.byref(nb), C.byref(nc)) == 0
+        return ms.value, nb.value, nc.value
 
     def exchange(c):
         ptr, cnt = C.c_void_p(), (C.c_long * 1)()
@@ -1225,10 +1235,14 @@ def test_rccl_allgather_of_one_rank_and_block_size_protocol():
 
     exchange(small)
     assert L.tjamd_comm_collectives(comm) == 2                 # counts, then the block
+    t, b, n = last()
+    assert n == 2 and 0.0 < t < 1000.0 and b >= small.n_kept * 24 + 16        # (what bench.py --gpus N reports per exchange)
     exchange(small)
     assert L.tjamd_comm_collectives(comm) == 3                 # the block size is agreed: one collective
+    assert last()[2] == 1
     exchange(big)                                              # does not fit the agreed block: one wasted, then counts + block
     assert L.tjamd_comm_collectives(comm) == 6
+    assert last()[2] == 3 and last()[1] >= big.n_kept * 24
     exchange(big)
     assert L.tjamd_comm_collectives(comm) == 7
     L.tjamd_comm_destroy(comm)
