@@ -505,6 +505,17 @@ class Counter:
     def last_partition_ms(self):
         return lib().tjamd_last_partition_ms(self._h)
 
+    def bucket_counts(self):
+        """raw records per hash bucket (diagnostic: tjamd_debug_bucket_counts; synchronises)"""
+        import numpy as np
+        f = lib().tjamd_debug_bucket_counts
+        f.restype = C.c_long
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        b = np.zeros(256, np.uint32)
+        if f(self._h, b.ctypes.data, 256) < 0:
+            raise TatajubaAmdError(_err())
+        return b
+
     def last_merge_ms(self):
         lib().tjamd_last_merge_ms.restype = C.c_double
         lib().tjamd_last_merge_ms.argtypes = [C.c_void_p]

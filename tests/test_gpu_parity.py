@@ -824,16 +824,29 @@ def test_full_size_properties_config2():
     assert c.download_kept().tobytes() == kept.tobytes() and c.coverage == cov
     # repeatability: the same resident stream scanned 150 times gives the same raw count every time (a race between the
     # waves of a workgroup over the staged-record count once lost some eighty records in one scan out of fifty)
+    _repeat_scans(c, s, m, raw, 150)
+    c.close()
+
+
+def _repeat_scans(c, s, m, raw, n):
+    """The same resident stream scanned n times: the same raw count AND the same count in every hash bucket each time.  (How
+    round 3's lost-record race showed: one scan in fifty came out some eighty records short, spread over sixty buckets.)"""
     import torch
     dev = torch.from_numpy(s).cuda()
+    c.reset()
+    c.scan_device(dev.data_ptr(), s.size, m)
+    assert c.raw_count() == raw
+    want = c.bucket_counts()
+    assert int(want.sum()) == raw
     bad = []
-    for it in range(150):
+    for it in range(n):
         c.reset()
         c.scan_device(dev.data_ptr(), s.size, m)
-        if c.raw_count() != raw:
-            bad.append((it, c.raw_count() - raw))
+        got = c.bucket_counts()
+        if c.raw_count() != raw or (got != want).any():
+            bad.append((it, c.raw_count() - raw, int((got != want).sum())))
+    del dev
     assert not bad, bad
-    c.close()
 
 
 def _sorted_desc(kept, d):
@@ -876,6 +889,8 @@ def test_full_size_properties_config3():
     c.scan_host(_revcomp_stream(s, L), m)
     assert c.raw_count() == raw and c.finalise(1, 5) == 0
     assert c.download_kept().tobytes() == kept.tobytes() and c.coverage == cov
+    # repeatability of the two-word kernel's passes (k > 12: the scan kernel partitions its 1536-record passes itself), pieces included
+    _repeat_scans(c, s, m, raw, 30)
     c.close()
 
 
@@ -907,6 +922,7 @@ def test_full_size_properties_config5():
     d2 = tj.decode_meta(k2["meta"])
     assert (k2["ctx0"] == kept["ctx0"]).all() and (k2["ctx1"] == kept["ctx1"]).all() and (d2["count"] == 2 * d["count"]).all()
     assert c.coverage == 2 * cov
+    _repeat_scans(c, s, m, raw, 30)                             # (long reads, k = 25: the two-word kernel again, tracts walked past the window's end)
     c.close()
 
 
