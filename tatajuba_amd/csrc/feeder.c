@@ -478,7 +478,25 @@ typedef struct
   int n_threads;
   tjz_block *blk;
   size_t blk_cap;
+  /* a member that is not BGZF on several threads (tjz_round): the stream is entered at block starts found by trial
+   * (tj_inflate.c: tjp_*), a round of stretches at a time */
+  int par;              /* allowed: more than one thread, the feeder's own inflater */
+  int par_active;       /* the member at hand is being decoded that way: pbit is a block boundary, hist the output in front of it */
+  int par_final;        /* ... and its final block has been decoded (pout holds the rest of its bytes) */
+  int par_giveup;       /* ... and the last round said that one decoder does this file better: it takes over once pout is handed out */
+  size_t pbit;
+  unsigned char *pout;  /* a round's bytes, handed out view by view */
+  size_t pout_cap, pout_len, pout_pos;
+  unsigned long pout_crc;       /* CRC-32 of pout[0, pout_len) (worked out by the threads that made the bytes) */
+  tjp_segment seg[TJF_MAX_THREADS];
+  size_t seg_bytes;     /* compressed bytes per stretch */
+  long par_rounds, par_stretches, par_false;    /* diagnostics */
+  double t_decode, t_resolve, t_handout;        /* (TATAJUBA_AMD_FEEDER_TRACE) */
 } tjz_source;
+
+static long tjf_stat_gz_rounds = 0, tjf_stat_gz_stretches = 0, tjf_stat_gz_false = 0;   /* of the last gzip file (tests) */
+long tjf_last_gz_stretches (void) { return tjf_stat_gz_stretches; }
+long tjf_last_gz_false_starts (void) { return tjf_stat_gz_false; }
 
 /* a BGZF block header at p (avail bytes there)?  -> its total size, 0 if it is not one / not whole */
 static size_t
@@ -574,6 +592,171 @@ tjz_member_header (const unsigned char *p, size_t avail)
   return x < avail ? x : 0;
 }
 
+/* ---- one member on several threads ----------------------------------------------------------------------------------
+ * A round: n stretches of seg_bytes compressed bytes from the known block boundary pbit on.  Stretch 0 starts there;
+ * every other one at the first bit position behind its nominal start that passes for the start of a block of text
+ * (tjp_find_block), if there is one.  All are decoded side by side, the window in front of a stretch unknown (16-bit
+ * symbols), each up to the first block boundary at or behind the NEXT stretch's start.  Then the check that makes the
+ * result exact whatever the search believed: a stretch is used only if the decoder of the stretch before it stopped
+ * precisely on its first bit -- the concatenation is then what one decoder running through would have produced; at the
+ * first stretch that was not reached that way the round ends and the next one starts where the last good decoder
+ * stopped.  The symbols become bytes window by window (the 32 KiB tails one after the other, the bulk side by side). */
+typedef struct
+{
+  tjz_source *s;
+  int j, n;
+  size_t nominal_bit, round_end_bit;
+  size_t start_bit;             /* (size_t) -1: no block start found */
+  size_t *starts;               /* all stretches' start_bit, read behind the barrier */
+  pthread_barrier_t *bar;
+  int rc;
+} tjz_stretch_job;
+
+static void *
+tjz_stretch_run (void *arg)
+{
+  tjz_stretch_job *k = (tjz_stretch_job *) arg;
+  tjz_source *s = k->s;
+  size_t stop;
+  int i;
+  if (k->j > 0) k->start_bit = tjp_find_block (s->z, s->zn, k->nominal_bit, k->nominal_bit + s->seg_bytes * 4);   /* (half a stretch) */
+  k->starts[k->j] = k->start_bit;
+  pthread_barrier_wait (k->bar);
+  k->rc = -2;
+  if (k->start_bit == (size_t) -1) return NULL;
+  stop = k->round_end_bit;
+  for (i = k->j + 1; i < k->n; i++) if (k->starts[i] != (size_t) -1) { stop = k->starts[i]; break; }
+  k->rc = tjp_decode (s->z, s->zn, k->start_bit, stop, &s->seg[k->j]);
+  return NULL;
+}
+
+typedef struct { const unsigned short *sym; size_t n; const unsigned char *win; size_t win_valid; unsigned char *out; int rc; unsigned crc; } tjz_resolve_job;
+static void *
+tjz_resolve_run (void *arg)
+{ /* symbols -> bytes, and the bytes' CRC-32 while they are in the cache (combined in order by the caller) */
+  tjz_resolve_job *r = (tjz_resolve_job *) arg;
+  size_t i;
+  r->rc = 0; r->crc = 0;
+  for (i = 0; i < r->n; i += 1u << 18) {
+    const size_t m = r->n - i < (1u << 18) ? r->n - i : (1u << 18);
+    if (tjp_resolve (r->sym + i, m, r->win, r->win_valid, r->out + i)) r->rc = -1;
+    r->crc = tji_crc32 (r->crc, r->out + i, m);
+  }
+  return NULL;
+}
+
+/* 0: pout holds the round's bytes (possibly none, when par_final is set); -1: the stream is damaged at pbit; 1: nothing
+ * came of it that a single decoder would not do better (no block start found in any stretch): the caller switches over */
+static int
+tjz_round (tjz_source *s, unsigned char *direct, size_t direct_room, size_t *direct_got)
+{ /* direct: where the caller wants the bytes (a view with direct_room bytes free); the round's first *direct_got bytes go
+   * there, whole stretches only, the rest to pout -- no copy for what fits */
+  tjz_stretch_job job[TJF_MAX_THREADS];
+  tjz_resolve_job res[TJF_MAX_THREADS];
+  pthread_t th[TJF_MAX_THREADS];
+  int started[TJF_MAX_THREADS], chain[TJF_MAX_THREADS];
+  size_t starts[TJF_MAX_THREADS];
+  unsigned char (*win)[32768] = NULL;
+  size_t win_valid[TJF_MAX_THREADS + 1];
+  pthread_barrier_t bar;
+  const size_t base = s->pbit >> 3, end_bit = s->zn * 8;
+  size_t total = 0, off;
+  int n = s->n_threads, j, nc = 0, rc = 0, n_direct = 0;
+  if (n > TJF_MAX_THREADS) n = TJF_MAX_THREADS;
+  while (n > 1 && base + (size_t) (n - 1) * s->seg_bytes + 65536 >= s->zn) n--;     /* stretches that would begin at the file's end */
+  if (pthread_barrier_init (&bar, NULL, (unsigned) n)) return -1;
+  for (j = 0; j < n; j++) {
+    job[j].s = s; job[j].j = j; job[j].n = n; job[j].starts = starts; job[j].bar = &bar; job[j].rc = -2;
+    job[j].nominal_bit = (base + (size_t) j * s->seg_bytes) * 8;
+    job[j].round_end_bit = (base + (size_t) n * s->seg_bytes) * 8;
+    if (job[j].round_end_bit > end_bit) job[j].round_end_bit = end_bit;
+    job[j].start_bit = j ? (size_t) -1 : s->pbit;
+    started[j] = 0;
+  }
+  for (j = 1; j < n; j++) {
+    if (pthread_create (&th[j], NULL, tjz_stretch_run, &job[j]) == 0) started[j] = 1;
+    else { pthread_barrier_destroy (&bar); while (--j >= 1) if (started[j]) pthread_cancel (th[j]); return -1; }   /* (no thread: give up on this file) */
+  }
+  { const double t_ = tjf_now ();
+  tjz_stretch_run (&job[0]);
+  for (j = 1; j < n; j++) if (started[j]) pthread_join (th[j], NULL);
+  s->t_decode += tjf_now () - t_; }
+  pthread_barrier_destroy (&bar);
+  s->par_rounds++;
+  /* the chain of stretches each of which was reached by the decoder of the one before */
+  *direct_got = 0;
+  if (job[0].rc != 0 && s->seg[0].n == 0) { s->pout_len = s->pout_pos = 0; return 1; }   /* no block decoded at pbit: the single decoder says what is wrong, if anything */
+  chain[nc++] = 0;
+  for (;;) {
+    const int a = chain[nc - 1];
+    int b;
+    if (job[a].rc != 0 || s->seg[a].is_final) break;   /* (an error: the blocks in front of it are good, the next round meets it again at its start) */
+    for (b = a + 1; b < n && job[b].start_bit == (size_t) -1; b++) ;
+    if (b >= n) break;
+    if (s->seg[a].end_bit != job[b].start_bit) { s->par_false++; break; }
+    chain[nc++] = b;
+  }
+  s->par_stretches += nc;
+  for (j = 0; j < nc; j++) total += s->seg[chain[j]].n;
+  {
+    /* stretches that fit the caller's view whole go there, the others to pout */
+    size_t fit = 0, rest;
+    for (j = 0; j < nc && fit + s->seg[chain[j]].n <= direct_room; j++) fit += s->seg[chain[j]].n;
+    n_direct = j; *direct_got = fit; rest = total - fit;
+    if (rest > s->pout_cap) {
+      free (s->pout);
+      s->pout_cap = rest + (rest >> 2) + 65536;
+      s->pout = (unsigned char *) malloc (s->pout_cap);
+      if (!s->pout) { s->pout_cap = 0; return -1; }
+    }
+  }
+  /* windows: the bytes in front of every stretch of the chain (the member's output so far for the first) */
+  const double t_res0 = tjf_now ();
+  win = (unsigned char (*)[32768]) malloc ((size_t) (nc + 1) * 32768);
+  if (!win) return -1;
+  memset (win[0], 0, 32768);
+  memcpy (win[0] + 32768 - s->hist_len, s->hist, s->hist_len);
+  win_valid[0] = s->hist_len;
+  for (j = 0; j < nc; j++) {
+    const tjp_segment *g = &s->seg[chain[j]];
+    const size_t tail = g->n < 32768 ? g->n : 32768;
+    if (tail < 32768) memcpy (win[j + 1], win[j] + tail, 32768 - tail);          /* (what stays of the window in front) */
+    if (tjp_resolve (TJP_SYMBOLS (g) + (g->n - tail), tail, win[j], win_valid[j], win[j + 1] + 32768 - tail)) rc = -1;
+    win_valid[j + 1] = win_valid[j] + tail > 32768 ? 32768 : win_valid[j] + tail;
+  }
+  /* the bulk, side by side */
+  off = 0;
+  for (j = 0; j < nc; j++) {
+    const tjp_segment *g = &s->seg[chain[j]];
+    if (j == n_direct) off = 0;                         /* (from here on: pout) */
+    res[j].sym = TJP_SYMBOLS (g); res[j].n = g->n; res[j].win = win[j]; res[j].win_valid = win_valid[j];
+    res[j].out = (j < n_direct ? direct : s->pout) + off; res[j].rc = 0;
+    off += g->n;
+    started[j] = 0;
+    if (j && pthread_create (&th[j], NULL, tjz_resolve_run, &res[j]) == 0) started[j] = 1;
+  }
+  for (j = 0; j < nc; j++) { if (!started[j]) tjz_resolve_run (&res[j]); }
+  for (j = 1; j < nc; j++) if (started[j]) pthread_join (th[j], NULL);
+  for (j = 0; j < nc; j++) if (res[j].rc) rc = -1;      /* a match that reaches in front of the member's first byte */
+  /* the member's CRC-32 and size so far: the direct part now, pout's part as it is handed out (crc of the whole of pout is known: kept) */
+  for (j = 0; j < n_direct; j++) { s->crc = crc32_combine (s->crc, res[j].crc, (z_off_t) res[j].n); s->isize += res[j].n; }
+  s->pout_crc = 0;
+  for (j = n_direct; j < nc; j++) s->pout_crc = crc32_combine (s->pout_crc, res[j].crc, (z_off_t) res[j].n);
+  if (!rc) {
+    const tjp_segment *last = &s->seg[chain[nc - 1]];
+    memcpy (s->hist, win[nc], 32768); s->hist_len = win_valid[nc];
+    if (s->hist_len < 32768) memmove (s->hist, s->hist + 32768 - s->hist_len, s->hist_len);    /* (hist holds its bytes from index 0) */
+    s->pbit = last->end_bit;
+    s->par_final = last->is_final;
+    s->pout_len = total - *direct_got; s->pout_pos = 0;
+    /* nothing but stretch 0 and no other block start found anywhere: a file this does nothing for (not text, or one block) */
+    if (!rc && nc == 1 && n > 1 && !last->is_final) { int any = 0; for (j = 1; j < n; j++) any |= job[j].start_bit != (size_t) -1; if (!any) rc = 1; }
+  }
+  free (win);
+  s->t_resolve += tjf_now () - t_res0;
+  return rc;
+}
+
 /* the next inflated bytes of the file into out[0, cap) (cap >= 64 KiB); 0 only when nothing is left */
 static size_t
 tjz_fill (tjz_source *s, unsigned char *out, size_t cap)
@@ -634,14 +817,54 @@ tjz_fill (tjz_source *s, unsigned char *out, size_t cap)
         if (!s->inf) { s->ended = 1; s->damaged = 1; break; }
         tji_init (s->inf);
         s->zpos += h; s->strm_open = 1; s->crc = crc32 (0L, Z_NULL, 0); s->isize = 0; s->hist_len = 0;
+        /* a member worth several stretches: on all threads (tjz_round) */
+        s->par_active = s->par && s->zn - s->zpos > 4 * s->seg_bytes;
+        s->par_final = 0; s->par_giveup = 0; s->pbit = s->zpos * 8; s->pout_len = s->pout_pos = 0;
       }
-      else if (got == 0 && s->hist_len) memcpy (out - s->hist_len, s->hist, s->hist_len);   /* (the room is there: feeder views keep >= 64 KiB in front) */
+      if (s->par_active) {
+        if (s->pout_pos < s->pout_len) {                /* a round's bytes, as many as the view takes */
+          size_t m = s->pout_len - s->pout_pos;
+          const double t_ = tjf_now ();
+          if (m > cap - got) m = cap - got;
+          memcpy (out + got, s->pout + s->pout_pos, m);
+          if (s->pout_pos == 0 && m == s->pout_len) s->crc = crc32_combine (s->crc, s->pout_crc, (z_off_t) m);   /* (the usual case: known already) */
+          else s->crc = tjz_crc_extend (s->crc, out + got, m, s->n_threads);
+          s->isize += m; s->pout_pos += m; got += m;
+          s->t_handout += tjf_now () - t_;
+          continue;
+        }
+        if (s->par_final) {                             /* the member's last byte has been handed out: its trailer */
+          s->zpos = (s->pbit + 7) >> 3;
+          s->par_active = 0; s->strm_open = 0; s->hist_len = 0;
+          rc = TJI_DONE;
+          goto member_done;
+        }
+        {
+          size_t dg = 0;
+          rc = s->par_giveup ? 1 : tjz_round (s, out + got, cap - got, &dg);
+          got += dg;
+        }
+        if (rc < 0) { s->ended = 1; s->damaged = 1; break; }
+        if (rc == 1 && s->pout_pos < s->pout_len) { s->par_giveup = 1; continue; }     /* (what the round did decode goes out first) */
+        if (rc == 1) {                                  /* no use here (not text, one huge block, ...): the single decoder from pbit on */
+          s->par_active = 0; s->par_giveup = 0;
+          tji_init (s->inf);
+          s->zpos = s->pbit >> 3;
+          if (s->pbit & 7u) { s->inf->bitbuf = (unsigned long long) s->z[s->zpos] >> (s->pbit & 7u); s->inf->bitcnt = 8u - (unsigned) (s->pbit & 7u); s->zpos++; }
+          /* (it wants the member's last 32 KiB right in front of what it writes, which tjz_fill arranges at the start of a
+           * view only: what this view holds goes out first) */
+          if (got) break;
+        }
+        continue;
+      }
+      if (got == 0 && s->hist_len) memcpy (out - s->hist_len, s->hist, s->hist_len);   /* (the room is there: feeder views keep >= 64 KiB in front) */
       ip = s->zpos;
       rc = tji_inflate (s->inf, s->z, s->zn, &ip, out + got, cap - got, &op, got == 0 ? s->hist_len : 0);
       s->zpos = ip;
       s->crc = tjz_crc_extend (s->crc, out + got, op, s->n_threads);
       s->isize += op;
       if (rc == TJI_DONE) {
+      member_done:
         s->strm_open = 0; s->hist_len = 0;
         if (s->zn - s->zpos < 8) { s->ended = 1; s->damaged = 1; }
         else {
@@ -696,6 +919,36 @@ tjz_fill (tjz_source *s, unsigned char *out, size_t cap)
 typedef struct { tjz_source *src; unsigned char *out; size_t cap, got; } tjz_fill_job;
 static void *tjz_fill_thread (void *arg) { tjz_fill_job *f = (tjz_fill_job *) arg; f->got = tjz_fill (f->src, f->out, f->cap); return NULL; }
 
+/* The buffers of a gzip file -- two views, the round's bytes, the stretches' symbols: some 300 MB -- are kept for the next
+ * file instead of going back to the allocator: a sample is read as several files (R1, R2, and the caller runs one thread
+ * per sample), and first-touch page faults on fresh buffers were a quarter of a 70 MB file's time.  Up to TJZ_KEEP sets. */
+#define TJZ_KEEP 8
+typedef struct { int used; unsigned char *view[2]; size_t view_cap[2], head[2]; unsigned char *pout; size_t pout_cap; tjp_segment seg[TJF_MAX_THREADS]; } tjz_buffers;
+static tjz_buffers tjz_kept[TJZ_KEEP];
+static pthread_mutex_t tjz_kept_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int
+tjz_take_buffers (tjz_buffers *b, size_t want_view_cap)
+{
+  int i, got = 0;
+  memset (b, 0, sizeof *b);
+  pthread_mutex_lock (&tjz_kept_lock);
+  for (i = 0; i < TJZ_KEEP && !got; i++)
+    if (tjz_kept[i].used && tjz_kept[i].view_cap[0] == want_view_cap && tjz_kept[i].view_cap[1] == want_view_cap) { *b = tjz_kept[i]; tjz_kept[i].used = 0; got = 1; }
+  pthread_mutex_unlock (&tjz_kept_lock);
+  return got;
+}
+
+static void
+tjz_keep_buffers (tjz_buffers *b)
+{
+  int i, j, kept = 0;
+  pthread_mutex_lock (&tjz_kept_lock);
+  for (i = 0; i < TJZ_KEEP && !kept; i++) if (!tjz_kept[i].used) { tjz_kept[i] = *b; tjz_kept[i].used = 1; kept = 1; }
+  pthread_mutex_unlock (&tjz_kept_lock);
+  if (!kept) { free (b->view[0]); free (b->view[1]); free (b->pout); for (j = 0; j < TJF_MAX_THREADS; j++) free (b->seg[j].buf); }
+}
+
 long
 tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const tjf_sink *sink)
 {
@@ -705,6 +958,7 @@ tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const t
   size_t view_cap[2] = {0, 0}, head[2];                 /* view[i] holds payload at [head[i], head[i] + got) */
   size_t reserve = 1u << 20, payload;
   tjz_fill_job fj;
+  tjz_buffers kept;
   pthread_t fth;
   int cur = 0, fill_running = 0, fill_threaded = 0;
   size_t carry_len = 0;
@@ -722,9 +976,22 @@ tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const t
   { size_t d; src.bgzf = tjz_bgzf_block (src.z, src.zn, &d) != 0; }
   src.n_threads = n_threads < 1 ? 1 : (n_threads > TJF_MAX_THREADS ? TJF_MAX_THREADS : n_threads);
   { const char *e = getenv ("TATAJUBA_AMD_FEEDER_INFLATE"); src.use_zlib = e && !strcmp (e, "zlib"); }
-  tjf_stat_windows = 0; tjf_stat_fallback = 0; tjf_stat_bgzf = 0;
+  {
+    /* a member that is not BGZF: on all threads, 1 MiB of compressed bytes per stretch (TATAJUBA_AMD_GZ_STRETCH: tests;
+     * TATAJUBA_AMD_GZ_PARALLEL=0: one decoder as before) */
+    const char *e = getenv ("TATAJUBA_AMD_GZ_STRETCH"), *d = getenv ("TATAJUBA_AMD_GZ_PARALLEL");
+    src.seg_bytes = e && atol (e) >= 65536 ? (size_t) atol (e) : ((size_t) 1 << 20);
+    src.par = src.n_threads > 1 && !src.use_zlib && !(d && !strcmp (d, "0"));
+  }
+  tjf_stat_windows = 0; tjf_stat_fallback = 0; tjf_stat_bgzf = 0; tjf_stat_gz_rounds = 0; tjf_stat_gz_stretches = 0; tjf_stat_gz_false = 0;
   if (tjf_state_init (&s, sink, n_threads, window_bytes + reserve)) { tjf_state_free (&s); munmap ((void *) src.z, src.zn); return -2; }
-  for (cur = 0; cur < 2; cur++) {
+  if (tjz_take_buffers (&kept, reserve + payload)) {
+    int j;
+    for (cur = 0; cur < 2; cur++) { view[cur] = kept.view[cur]; view_cap[cur] = kept.view_cap[cur]; head[cur] = reserve; }
+    src.pout = kept.pout; src.pout_cap = kept.pout_cap;
+    for (j = 0; j < TJF_MAX_THREADS; j++) src.seg[j] = kept.seg[j];
+  }
+  else for (cur = 0; cur < 2; cur++) {
     view_cap[cur] = reserve + payload; head[cur] = reserve;
     view[cur] = (unsigned char *) malloc (view_cap[cur]);
     if (!view[cur]) { s.total_reads = -2; s.done = 1; }
@@ -768,10 +1035,26 @@ tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const t
   if (src.strm_open && src.use_zlib) inflateEnd (&src.strm);
   free (src.inf);
   free (src.blk);
-  free (view[0]); free (view[1]);
+  tjf_stat_gz_rounds = src.par_rounds; tjf_stat_gz_stretches = src.par_stretches; tjf_stat_gz_false = src.par_false;
+  if (view[0] && view[1] && view_cap[0] == reserve + payload && view_cap[1] == reserve + payload && payload >= ((size_t) 1 << 20)) {
+    int j;
+    for (cur = 0; cur < 2; cur++) { kept.view[cur] = view[cur]; kept.view_cap[cur] = view_cap[cur]; kept.head[cur] = reserve; }
+    kept.pout = src.pout; kept.pout_cap = src.pout_cap;
+    for (j = 0; j < TJF_MAX_THREADS; j++) kept.seg[j] = src.seg[j];
+    tjz_keep_buffers (&kept);
+  }
+  else {
+    int j;
+    free (src.pout);
+    for (j = 0; j < TJF_MAX_THREADS; j++) free (src.seg[j].buf);
+    free (view[0]); free (view[1]);
+  }
   tjf_state_free (&s);
   munmap ((void *) src.z, src.zn);
   tjf_trace (&s, path, tjf_stat_bgzf ? "bgzf" : "gzip", t0, t_inflate);
+  if (src.par_rounds && getenv ("TATAJUBA_AMD_FEEDER_TRACE"))
+    fprintf (stderr, "[feeder]   one member on %d threads: %ld rounds, %ld stretches used, %ld false starts; search + decode %.1f ms, resolve %.1f ms, hand-out + CRC %.1f ms\n",
+             src.n_threads, src.par_rounds, src.par_stretches, src.par_false, src.t_decode * 1e3, src.t_resolve * 1e3, src.t_handout * 1e3);
   total = s.total_reads;
   if (src.crc_failed && total >= 0) total = -4;         /* (what was handed to the sink cannot be trusted) */
   return total;

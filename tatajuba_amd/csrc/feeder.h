@@ -28,6 +28,8 @@ long tjf_parse_file (const char *path, int n_threads, size_t window_bytes, const
  * with TATAJUBA_AMD_FEEDER_INFLATE=zlib).  Same return values, and -4 if a member did not match its own CRC-32 / size
  * after it had been handed on (a damaged file, or a decoder fault: either way the counter's content is void). */
 long tjf_parse_gz_file (const char *path, int n_threads, size_t window_bytes, const tjf_sink *sink);
+long tjf_last_gz_stretches (void);                          /* stretches of other gzip members decoded side by side and used (tjz_round) */
+long tjf_last_gz_false_starts (void);                       /* ... block starts found by trial that the decoder in front did not arrive at */
 long tjf_last_bgzf_blocks (void);                           /* BGZF members the last call inflated side by side */
 
 /* diagnostics of the last call in this process: windows that came whole from the parallel readers, windows that one reader had to finish */

@@ -374,6 +374,9 @@ tjamd_read_file_stream_mt (const char *path, unsigned char *out, long capacity, 
 /* diagnostic (not in the public header): windows the feeder accepted in its last call, and whether it fell back */
 long tjamd_debug_feeder_stats (long *fell_back) { long w = 0; tjf_last_stats (&w, fell_back); return w; }
 long tjamd_debug_feeder_bgzf_blocks (void) { return tjf_last_bgzf_blocks (); }
+/* stretches of a one-member gzip file that were decoded side by side and used / block starts that turned out not to be */
+long tjamd_debug_feeder_gz_stretches (void) { return tjf_last_gz_stretches (); }
+long tjamd_debug_feeder_gz_false_starts (void) { return tjf_last_gz_false_starts (); }
 
 unsigned tjamd_debug_crc32 (const unsigned char *p, long n) { return tji_crc32 (0u, p, (size_t) n); }
 

@@ -10,6 +10,10 @@
  */
 #include "tj_inflate.h"
 #include <string.h>
+#include <stdlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <pthread.h>
 
 #define LIT_TABLE_BITS   11
@@ -387,6 +391,335 @@ save:
   *in_pos = (size_t) (in - in0);
   *out_pos = (size_t) (out - out0);
   return rc;
+}
+
+/* ---- entering a DEFLATE stream in the middle (feeder.c: a one-member .gz file on more than one thread) -------------
+ * A deflate stream can only be decoded from a block start, and from there only up to references into the 32 KiB of
+ * output in front of it.  So: (1) tjp_find_block looks for a bit position at which a dynamic-Huffman block header
+ * parses, its codes are complete, the block decodes to text and is followed by something that looks like a block
+ * header again; (2) tjp_decode decodes from such a position with the window in front UNKNOWN: its output is 16-bit
+ * symbols, a byte or 256 + i for "byte i of the unknown window" (a match that reaches into the window copies those
+ * markers, a match into the segment's own output copies whatever stands there); (3) tjp_resolve turns the symbols
+ * into bytes once the window is known.  Whether a position found by (1) really was a block start is not a matter of
+ * trust: the decoder of the stretch in front must arrive at exactly that bit position at a block boundary -- then the
+ * bytes are the bytes a decoder running from the member's start would have produced -- and otherwise the speculative
+ * stretch is thrown away (feeder.c).  The member's CRC-32 and size are checked as for any other member. */
+#define TJP_WIN 32768u
+
+static unsigned long long
+tjp_peek (const unsigned char *z, size_t zn, size_t bitpos)
+{ /* >= 57 bits of the stream from bitpos on (zeros behind its end) */
+  const size_t b = bitpos >> 3;
+  unsigned long long v = 0;
+  if (b + 8 <= zn) memcpy (&v, z + b, 8);
+  else { size_t i; for (i = 0; b + i < zn && i < 8; i++) v |= (unsigned long long) z[b + i] << (8 * i); }
+  return v >> (bitpos & 7u);
+}
+
+typedef struct { unsigned lit[TJI_LIT_TABLE_CAP], dist[TJI_DIST_TABLE_CAP], single[2048]; } tjp_tables;   /* lit: primary entries hold up to three literals (pair_literals), single: one symbol per entry */
+
+/* block header at *pos: 0 = stored (then *stored_len, *pos at its first byte), 1 / 2 = coded (tables built, *pos at the first
+ * symbol), -1 = not a valid header.  *is_final = BFINAL. */
+static int
+tjp_header (const unsigned char *z, size_t zn, size_t *pos, tjp_tables *t, int *is_final, unsigned *stored_len)
+{
+  size_t p = *pos;
+  unsigned long long b;
+  unsigned type;
+  if ((p >> 3) >= zn) return -1;
+  b = tjp_peek (z, zn, p);
+  *is_final = (int) (b & 1u);
+  type = (unsigned) (b >> 1) & 3u;
+  p += 3;
+  if (type == 0) {
+    unsigned len, nlen;
+    p = (p + 7u) & ~(size_t) 7u;
+    if ((p >> 3) + 4 > zn) return -1;
+    len = (unsigned) z[p >> 3] | ((unsigned) z[(p >> 3) + 1] << 8);
+    nlen = (unsigned) z[(p >> 3) + 2] | ((unsigned) z[(p >> 3) + 3] << 8);
+    if ((len ^ nlen) != 0xffffu) return -1;
+    p += 32;
+    if ((p >> 3) + len > zn) return -1;
+    *stored_len = len; *pos = p;
+    return 0;
+  }
+  if (type == 1) {
+    unsigned char lens[N_LITLEN + N_DIST];
+    int i;
+    for (i = 0; i < 144; i++) lens[i] = 8;
+    for (; i < 256; i++) lens[i] = 9;
+    for (; i < 280; i++) lens[i] = 7;
+    for (; i < 288; i++) lens[i] = 8;
+    for (i = 0; i < 32; i++) lens[N_LITLEN + i] = 5;
+    if (build_table (t->lit, LIT_TABLE_BITS, TJI_LIT_TABLE_CAP, lens, 288, 1)) return -1;
+    if (build_table (t->dist, DIST_TABLE_BITS, TJI_DIST_TABLE_CAP, lens + N_LITLEN, 32, 2)) return -1;
+    pair_literals (t->lit, t->single);
+    *pos = p;
+    return 1;
+  }
+  if (type == 2) {
+    unsigned hlit, hdist, hclen, i, n;
+    unsigned char pre_lens[N_PRECODE], lens[N_LITLEN + N_DIST + 137], ll[N_LITLEN], dl[N_DIST];
+    unsigned pre_table[1u << 7];
+    b = tjp_peek (z, zn, p);
+    hlit = (unsigned) (b & 31u) + 257; hdist = (unsigned) ((b >> 5) & 31u) + 1; hclen = (unsigned) ((b >> 10) & 15u) + 4;
+    p += 14;
+    if (hlit > 286 || hdist > 30) return -1;
+    memset (pre_lens, 0, sizeof pre_lens);
+    b = tjp_peek (z, zn, p);                            /* 19 x 3 = 57 bits at most */
+    for (i = 0; i < hclen; i++) { pre_lens[precode_order[i]] = (unsigned char) (b & 7u); b >>= 3; }
+    p += 3 * hclen;
+    if (build_table (pre_table, 7, 1 << 7, pre_lens, N_PRECODE, 0)) return -1;
+    n = 0;
+    while (n < hlit + hdist) {
+      unsigned e, sym;
+      if ((p >> 3) >= zn) return -1;
+      b = tjp_peek (z, zn, p);
+      e = pre_table[b & 127u];
+      if (e & E_INVALID) return -1;
+      p += e & 0xffu; b >>= e & 0xffu;
+      sym = e >> 16;
+      if (sym < 16) lens[n++] = (unsigned char) sym;
+      else {
+        unsigned rep, val = 0;
+        if (sym == 16) { if (!n) return -1; val = lens[n - 1]; rep = 3 + (unsigned) (b & 3u); p += 2; }
+        else if (sym == 17) { rep = 3 + (unsigned) (b & 7u); p += 3; }
+        else { rep = 11 + (unsigned) (b & 127u); p += 7; }
+        if (n + rep > hlit + hdist) return -1;
+        while (rep--) lens[n++] = (unsigned char) val;
+      }
+    }
+    if (lens[256] == 0) return -1;
+    memset (ll, 0, sizeof ll); memset (dl, 0, sizeof dl);
+    memcpy (ll, lens, hlit); memcpy (dl, lens + hlit, hdist);
+    if (build_table (t->lit, LIT_TABLE_BITS, TJI_LIT_TABLE_CAP, ll, N_LITLEN, 1)) return -1;
+    if (build_table (t->dist, DIST_TABLE_BITS, TJI_DIST_TABLE_CAP, dl, N_DIST, 2)) return -1;
+    pair_literals (t->lit, t->single);
+    *pos = p;
+    return 2;
+  }
+  return -1;
+}
+
+/* The cheap part of tjp_header's test for a dynamic block, for the search: BFINAL = 0, BTYPE = 2, counts in range, the code
+ * length code complete.  Nearly every wrong position fails here. */
+static int
+tjp_header_plausible (const unsigned char *z, size_t zn, size_t p)
+{
+  const unsigned long long b = tjp_peek (z, zn, p);
+  unsigned hclen, i, left = 128;                        /* Kraft sum in units of 2^-7 */
+  unsigned long long c;
+  if ((b & 7u) != 4u) return 0;                         /* BFINAL 0, BTYPE 10 */
+  if (((b >> 3) & 31u) > 29u || ((b >> 8) & 31u) > 29u) return 0;
+  hclen = (unsigned) ((b >> 13) & 15u) + 4;
+  c = tjp_peek (z, zn, p + 17);
+  for (i = 0; i < hclen; i++) { const unsigned l = (unsigned) (c & 7u); c >>= 3; if (l) { const unsigned w = 128u >> l; if (w > left) return 0; left -= w; } }
+  return left == 0;
+}
+
+/* one coded block from *pos (first symbol) to behind its end-of-block code, for the search: nothing is written; -2 at the
+ * first literal that is no text byte, 1 once more than max_out bytes would have come out ("looks fine so far"), 0 at the
+ * block's end (*n = bytes it holds), -1 invalid */
+static int
+tjp_block_text (const unsigned char *z, size_t zn, size_t *pos, const tjp_tables *t, size_t *n, size_t max_out)
+{
+  size_t p = *pos, k = 0;
+  const size_t end_bit = zn * 8;
+  for (;;) {
+    unsigned long long b;
+    unsigned e;
+    if (p >= end_bit) return -1;
+    b = tjp_peek (z, zn, p);
+    e = t->single[b & ((1u << LIT_TABLE_BITS) - 1u)];
+    if (e & E_SUBTABLE) { p += e & 0xffu; b >>= e & 0xffu; e = t->lit[(e >> 16) + (unsigned) (b & ((1u << E_EXTRA (e)) - 1u))]; }
+    if (e & E_INVALID) return -1;
+    p += e & 0xffu; b >>= e & 0xffu;
+    if (e & E_LITERAL) {
+      const unsigned c = e >> 16;
+      if (!((c >= 32u && c < 127u) || c == '\n' || c == '\r' || c == '\t')) return -2;
+      if (++k > max_out) { *pos = p; *n = k; return 1; }
+      continue;
+    }
+    if (e & E_EOB) { *pos = p; *n = k; return 0; }
+    k += (e >> 16) + (unsigned) (b & ((1u << E_EXTRA (e)) - 1u));
+    p += E_EXTRA (e); b >>= E_EXTRA (e);
+    e = t->dist[b & ((1u << DIST_TABLE_BITS) - 1u)];
+    if (e & E_SUBTABLE) { p += e & 0xffu; b >>= e & 0xffu; e = t->dist[(e >> 16) + (unsigned) (b & ((1u << E_EXTRA (e)) - 1u))]; }
+    if (e & E_INVALID) return -1;
+    p += (e & 0xffu) + E_EXTRA (e);
+    if (k > max_out) { *pos = p; *n = k; return 1; }
+  }
+}
+
+/* the same block decoded: symbols appended at out[*n] (out[-TJP_WIN .. -1] is the window in front); `room` symbols fit.
+ * 0 at the block's end, -1 invalid, -3 out of room (nothing is kept: the caller comes again with more) */
+static int
+tjp_block (const unsigned char *z, size_t zn, size_t *pos, const tjp_tables *t, unsigned short *out, size_t *n, size_t room)
+{
+  size_t p = *pos, k = *n;
+  const size_t end_bit = zn * 8;
+  for (;;) {
+    unsigned long long b;
+    unsigned e, len, dist;
+    if (p >= end_bit) return -1;
+    if (k + 264 > room) return -3;                      /* (three literals or the longest match, written without further checks) */
+    b = tjp_peek (z, zn, p);
+    e = t->lit[b & ((1u << LIT_TABLE_BITS) - 1u)];
+    if (e & E_LITERAL) {                                /* a primary entry of literals: up to three, first | second << 8 in the value, the third in bits
+                                                         * 8-14 -- which are the other flags' bits: E_LITERAL is looked at first, as in the serial loop */
+      out[k] = (unsigned short) ((e >> 16) & 0xffu); out[k + 1] = (unsigned short) (e >> 24); out[k + 2] = (unsigned short) ((e >> 8) & 0x7fu);
+      k += E_LITN (e); p += e & 0xfu; b >>= e & 0xfu;
+      e = t->lit[b & ((1u << LIT_TABLE_BITS) - 1u)];    /* (57 bits were looked at: 11 are gone at most, 15 + 5 + 15 + 13 may follow) */
+      if (e & E_LITERAL) {
+        out[k] = (unsigned short) ((e >> 16) & 0xffu); out[k + 1] = (unsigned short) (e >> 24); out[k + 2] = (unsigned short) ((e >> 8) & 0x7fu);
+        k += E_LITN (e); p += e & 0xfu;
+        continue;
+      }
+    }
+    if (e & E_SUBTABLE) { p += e & 0xffu; b >>= e & 0xffu; e = t->lit[(e >> 16) + (unsigned) (b & ((1u << E_EXTRA (e)) - 1u))]; }
+    if (e & E_INVALID) return -1;
+    p += e & 0xffu; b >>= e & 0xffu;
+    if (e & E_LITERAL) { out[k++] = (unsigned short) (e >> 16); continue; }
+    if (e & E_EOB) { *pos = p; *n = k; return 0; }
+    len = (e >> 16) + (unsigned) (b & ((1u << E_EXTRA (e)) - 1u));
+    p += E_EXTRA (e); b >>= E_EXTRA (e);
+    e = t->dist[b & ((1u << DIST_TABLE_BITS) - 1u)];
+    if (e & E_SUBTABLE) { p += e & 0xffu; b >>= e & 0xffu; e = t->dist[(e >> 16) + (unsigned) (b & ((1u << E_EXTRA (e)) - 1u))]; }
+    if (e & E_INVALID) return -1;
+    p += e & 0xffu; b >>= e & 0xffu;
+    dist = (e >> 16) + (unsigned) (b & ((1u << E_EXTRA (e)) - 1u));
+    p += E_EXTRA (e);
+    {
+      unsigned short *d = out + k;
+      const unsigned short *src = d - dist;
+      unsigned i;
+      if (dist >= 4) { for (i = 0; i < len; i += 4) memcpy (d + i, src + i, 8); }       /* (four symbols at a time; up to three past the match: room is there) */
+      else for (i = 0; i < len; i++) d[i] = src[i];
+    }
+    k += len;
+  }
+}
+
+size_t
+tjp_find_block (const unsigned char *z, size_t zn, size_t from_bit, size_t limit_bit)
+{
+  tjp_tables *t = (tjp_tables *) malloc (sizeof (tjp_tables));
+  size_t p, found = (size_t) -1;
+  if (!t) return found;
+  if (limit_bit > zn * 8) limit_bit = zn * 8;
+  for (p = from_bit; p + 64 < limit_bit; p++) {
+    size_t q = p, n = 0;
+    int fin, rc;
+    unsigned sl;
+    if (!tjp_header_plausible (z, zn, p)) continue;
+    if (tjp_header (z, zn, &q, t, &fin, &sl) != 2) continue;
+    rc = tjp_block_text (z, zn, &q, t, &n, 1u << 20);
+    if (rc == 1) { found = p; break; }                  /* a megabyte of text out of one block: good enough */
+    if (rc != 0 || n < 64) continue;
+    /* the block ended: what follows must look like a block header too (a dynamic one: plausible; stored: LEN / NLEN agree;
+     * a fixed one cannot be told from noise, so such a position is passed over -- the next dynamic block will do) */
+    {
+      const unsigned long long b = tjp_peek (z, zn, q);
+      const unsigned type = (unsigned) (b >> 1) & 3u;
+      size_t q2 = q;
+      if (type == 2 && (b & 1u) == 0 && tjp_header_plausible (z, zn, q)) { found = p; break; }
+      if ((type == 0 || (type == 2 && (b & 1u))) && tjp_header (z, zn, &q2, t, &fin, &sl) >= 0) { found = p; break; }
+    }
+  }
+  free (t);
+  return found;
+}
+
+int
+tjp_decode (const unsigned char *z, size_t zn, size_t start_bit, size_t stop_bit, tjp_segment *seg)
+{
+  tjp_tables *t = (tjp_tables *) malloc (sizeof (tjp_tables));
+  size_t p = start_bit, n = 0, cap = seg->cap;
+  unsigned short *buf = seg->buf;                       /* buf[0 .. TJP_WIN) = the window's markers, symbols from buf[TJP_WIN] on */
+  int rc = -1;
+  seg->n = 0; seg->end_bit = start_bit; seg->is_final = 0;
+  if (!t) return -1;
+  if (!buf || cap < (1u << 20)) {
+    cap = (size_t) 8 << 20;
+    buf = (unsigned short *) realloc (buf, (TJP_WIN + cap) * sizeof (unsigned short));
+    if (!buf) { free (t); seg->buf = NULL; seg->cap = 0; return -1; }
+  }
+  { unsigned i; for (i = 0; i < TJP_WIN; i++) buf[i] = (unsigned short) (256u + i); }
+  for (;;) {
+    int fin, kind;
+    unsigned sl = 0;
+    if (p >= stop_bit) { rc = 0; break; }               /* at a block boundary at or behind the target */
+    if (n + 65536u + 258u + 1024u > cap) {               /* room for a stored block or a long stretch of coded output */
+      unsigned short *nb;
+      cap *= 2;
+      nb = (unsigned short *) realloc (buf, (TJP_WIN + cap) * sizeof (unsigned short));
+      if (!nb) break;
+      buf = nb;
+    }
+    kind = tjp_header (z, zn, &p, t, &fin, &sl);
+    if (kind < 0) break;
+    if (kind == 0) {
+      unsigned i;
+      const unsigned char *src = z + (p >> 3);
+      for (i = 0; i < sl; i++) buf[TJP_WIN + n + i] = src[i];
+      n += sl; p += (size_t) sl * 8;
+    }
+    else {
+      /* (a coded block can be longer than the room at hand -- zlib ends one after 16 K symbols, others need not: then more
+       * room, and the block again from its first symbol) */
+      for (;;) {
+        size_t q = p, k = n;
+        const int r = tjp_block (z, zn, &q, t, buf + TJP_WIN, &k, cap);
+        if (r == 0) { p = q; n = k; break; }
+        if (r == -3 && cap < ((size_t) 1 << 32)) {
+          unsigned short *nb;
+          cap *= 2;
+          nb = (unsigned short *) realloc (buf, (TJP_WIN + cap) * sizeof (unsigned short));
+          if (!nb) { kind = -1; break; }
+          buf = nb;
+          continue;
+        }
+        kind = -1; break;
+      }
+      if (kind < 0) break;
+    }
+    seg->end_bit = p; seg->n = n;
+    if (fin) { seg->is_final = 1; rc = 0; break; }
+  }
+  seg->buf = buf; seg->cap = cap;
+  if (rc == 0) { seg->n = n; seg->end_bit = p; }        /* (on an error: the last block boundary reached, set in the loop) */
+  free (t);
+  return rc;
+}
+
+int
+tjp_resolve (const unsigned short *sym, size_t n, const unsigned char *window, size_t win_valid, unsigned char *out)
+{ /* window[TJP_WIN - win_valid .. TJP_WIN) = the bytes in front; marker 256 + i = window[i] */
+  size_t i = 0;
+  unsigned bad = 0;
+  const size_t first_valid = TJP_WIN - win_valid;
+#if defined(__SSE2__)
+  /* sixteen symbols at a time while they are all plain bytes (nearly everything behind a stretch's first 32 KiB) */
+  for (; i + 16 <= n; i += 16) {
+    const __m128i a = _mm_loadu_si128 ((const __m128i *) (sym + i)), b = _mm_loadu_si128 ((const __m128i *) (sym + i + 8));
+    const __m128i hi = _mm_or_si128 (_mm_srli_epi16 (a, 8), _mm_srli_epi16 (b, 8));
+    if (_mm_movemask_epi8 (_mm_cmpeq_epi16 (hi, _mm_setzero_si128 ())) == 0xffff) { _mm_storeu_si128 ((__m128i *) (out + i), _mm_packus_epi16 (a, b)); continue; }
+    {
+      size_t j;
+      for (j = i; j < i + 16; j++) {
+        const unsigned v = sym[j];
+        if (v < 256u) out[j] = (unsigned char) v;
+        else { const unsigned w = v - 256u; bad |= (unsigned) (w < first_valid); out[j] = window[w]; }
+      }
+    }
+  }
+#endif
+  for (; i < n; i++) {
+    const unsigned v = sym[i];
+    if (v < 256u) out[i] = (unsigned char) v;
+    else { const unsigned w = v - 256u; bad |= (unsigned) (w < first_valid); out[i] = window[w]; }
+  }
+  return bad ? -1 : 0;
 }
 
 /* ---- CRC-32 (the gzip polynomial, reflected 0xEDB88320), slicing by 16: zlib 1.2.11's crc32() does 1 GB/s, which next to

@@ -32,6 +32,26 @@ void tji_init (tji_state *s);
 int tji_inflate (tji_state *s, const unsigned char *in, size_t in_len, size_t *in_pos, unsigned char *out, size_t out_cap, size_t *out_pos,
                  size_t hist_avail);
 
+/* ---- entering a stream in the middle (see tj_inflate.c): find a block start, decode with the window in front unknown
+ * (16-bit symbols: a byte, or 256 + i = byte i of that 32 KiB window), resolve once the window is known ---- */
+typedef struct
+{
+  unsigned short *buf;          /* 32768 window markers, then the symbols; (re)allocated by tjp_decode, freed by the caller */
+  size_t cap, n;                /* symbols that fit / decoded */
+  size_t end_bit;               /* the block boundary the decoder stopped at */
+  int is_final;                 /* ... which was the end of the final block */
+} tjp_segment;
+#define TJP_SYMBOLS(seg) ((seg)->buf + 32768)
+
+/* first bit position in [from_bit, limit_bit) that passes for the start of a dynamic-Huffman block of text; (size_t) -1: none */
+size_t tjp_find_block (const unsigned char *z, size_t zn, size_t from_bit, size_t limit_bit);
+/* decode block after block from start_bit (a block start) and stop at the first block boundary >= stop_bit, or behind the
+ * final block.  0: stopped at seg->end_bit; -1: invalid data (or out of memory) -- seg->n / end_bit then describe the
+ * blocks that did decode. */
+int tjp_decode (const unsigned char *z, size_t zn, size_t start_bit, size_t stop_bit, tjp_segment *seg);
+/* symbols -> bytes; window[32768 - win_valid, 32768) are the bytes in front.  -1: a symbol points in front of them. */
+int tjp_resolve (const unsigned short *sym, size_t n, const unsigned char *window, size_t win_valid, unsigned char *out);
+
 /* CRC-32 as in gzip (same values as zlib's crc32(); start with crc = 0) */
 unsigned tji_crc32 (unsigned crc, const unsigned char *p, size_t n);
 

@@ -311,6 +311,92 @@ def test_gzip_feeder_matches_gzread_on_adversarial_files(tmp_path, seed):
     assert _check_gz(p, raw, combos[:2]) == m
 
 
+def _fastq_text(n_reads, seed, L=150, quals=b"FFFF:FF,#"):
+    rng = np.random.default_rng(seed)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=(n_reads, L))]
+    q = np.frombuffer(quals, np.uint8)[rng.integers(0, len(quals), size=(n_reads, L))]
+    return b"".join(b"@r%d/1\n%s\n+\n%s\n" % (i, seq[i].tobytes(), q[i].tobytes()) for i in range(n_reads))
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_one_member_gzip_is_inflated_on_several_threads(tmp_path, monkeypatch, level):
+    """A .gz file of one member (what gzip(1) writes and the reference's gzopen usually gets, src/hopo_counter.c:142): the
+    deflate stream is entered at block starts found by trial, the stretches decoded side by side with the window in front
+    unknown and resolved afterwards; a stretch counts only if the decoder in front of it stopped exactly on its first bit
+    (csrc/feeder.c: tjz_round).  Same bytes as one reader over zlib's gzread, for every thread count and stretch size."""
+    import ctypes as C, gzip
+    from tatajuba_amd.capi import read_file_stream_mt
+    txt = _fastq_text(60000, 100 + level)
+    p = str(tmp_path / "one.fq.gz")
+    open(p, "wb").write(gzip.compress(txt, level))
+    exp, m = tj.read_file_stream(p)
+    assert m == 60000
+    L = tj.lib()
+    L.tjamd_debug_feeder_gz_stretches.restype = C.c_long
+    L.tjamd_debug_feeder_gz_false_starts.restype = C.c_long
+    for stretch, threads, window in ((1 << 20, 4, 8 << 20), (65536, 8, 1 << 20), (200000, 3, 65536), (65536, 2, 1 << 30)):
+        monkeypatch.setenv("TATAJUBA_AMD_GZ_STRETCH", str(stretch))
+        got, n = read_file_stream_mt(p, threads, window)
+        assert n == m and got.tobytes() == exp.tobytes(), (stretch, threads, window)
+        assert L.tjamd_debug_feeder_gz_stretches() > 2, "the member was not entered in the middle"
+    monkeypatch.setenv("TATAJUBA_AMD_GZ_PARALLEL", "0")       # one decoder, as before
+    got, n = read_file_stream_mt(p, 4, 1 << 20)
+    assert got.tobytes() == exp.tobytes() and L.tjamd_debug_feeder_gz_stretches() == 0
+
+
+def test_one_member_gzip_on_several_threads_odd_streams(tmp_path, monkeypatch):
+    """What the search for block starts must not be fooled by, and what it cannot use: stored blocks (level 0), a member
+    of fixed-code blocks, bytes that are no text (no block start is accepted: the single decoder takes over), several
+    members one after the other, a file cut short, garbage behind the member."""
+    import ctypes as C, gzip, zlib
+    from tatajuba_amd.capi import read_file_stream_mt
+    monkeypatch.setenv("TATAJUBA_AMD_GZ_STRETCH", "65536")
+    L = tj.lib()
+    L.tjamd_debug_feeder_gz_stretches.restype = C.c_long
+    txt = _fastq_text(20000, 7)
+
+    def member(data, **kw):
+        co = zlib.compressobj(wbits=31, **kw)
+        return co.compress(data) + co.flush()
+
+    def flushed(data, every):                                   # Z_FULL_FLUSH points: stored empty blocks between the coded ones
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        out = []
+        for i in range(0, len(data), every):
+            out.append(co.compress(data[i:i + every]))
+            out.append(co.flush(zlib.Z_FULL_FLUSH if (i // every) % 2 else zlib.Z_SYNC_FLUSH))
+        return b"".join(out) + co.flush()
+
+    cases = {"stored": member(txt, level=0), "fixed": member(txt, level=6, strategy=zlib.Z_FIXED), "huffman_only": member(txt, level=6, strategy=zlib.Z_HUFFMAN_ONLY),
+             "rle": member(txt, level=6, strategy=zlib.Z_RLE), "flush_points": flushed(txt, 30011),
+             "three_members": gzip.compress(txt[:len(txt) // 3], 9) + gzip.compress(txt[len(txt) // 3: len(txt) // 2], 1) + gzip.compress(txt[len(txt) // 2:], 6),
+             "garbage_behind": gzip.compress(txt, 6) + b"\0\0junk that is no gzip header"}
+    for name, blob in cases.items():
+        p = str(tmp_path / (name + ".fq.gz"))
+        open(p, "wb").write(blob)
+        exp, m = tj.read_file_stream(p)
+        assert m == 20000, name
+        for threads, window in ((4, 1 << 20), (7, 65536)):
+            got, n = read_file_stream_mt(p, threads, window)
+            assert n == m and got.tobytes() == exp.tobytes(), (name, threads, window)
+    # a FASTA record whose sequence line is not text to the search (bytes >= 0x80 are legal input to the reader): no block
+    # start is accepted anywhere, the single decoder does the file
+    rng = np.random.default_rng(5)
+    blob = b">x\n" + bytes(rng.integers(128, 256, size=3_000_000, dtype=np.uint8).tolist()) + b"\n>y\nACGT\n"
+    p = str(tmp_path / "binary.fa.gz")
+    open(p, "wb").write(gzip.compress(blob, 6))
+    exp, m = tj.read_file_stream(p)
+    got, n = read_file_stream_mt(p, 4, 1 << 20)
+    assert m == n == 2 and got.tobytes() == exp.tobytes() and L.tjamd_debug_feeder_gz_stretches() <= 2
+    # cut short in the middle of the stream: everything the single reader gets before the break, the same way
+    whole = gzip.compress(_fastq_text(30000, 9), 6)
+    p = str(tmp_path / "cut.fq.gz")
+    open(p, "wb").write(whole[: len(whole) * 2 // 3])
+    exp, m = tj.read_file_stream(p)
+    got, n = read_file_stream_mt(p, 4, 1 << 20)
+    assert n == m and got.tobytes() == exp.tobytes() and 10000 < m < 30000
+
+
 def test_gzip_feeder_records_longer_than_a_view_and_bad_quality(tmp_path):
     import gzip
     rng = np.random.default_rng(31)
