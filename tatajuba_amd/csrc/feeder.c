@@ -637,8 +637,8 @@ tjz_resolve_run (void *arg)
   tjz_resolve_job *r = (tjz_resolve_job *) arg;
   size_t i;
   r->rc = 0; r->crc = 0;
-  for (i = 0; i < r->n; i += 1u << 18) {
-    const size_t m = r->n - i < (1u << 18) ? r->n - i : (1u << 18);
+  for (i = 0; i < r->n; i += 1u << 20) {
+    const size_t m = r->n - i < (1u << 20) ? r->n - i : (1u << 20);
     if (tjp_resolve (r->sym + i, m, r->win, r->win_valid, r->out + i)) r->rc = -1;
     r->crc = tji_crc32 (r->crc, r->out + i, m);
   }

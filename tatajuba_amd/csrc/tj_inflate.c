@@ -698,6 +698,21 @@ tjp_resolve (const unsigned short *sym, size_t n, const unsigned char *window, s
   size_t i = 0;
   unsigned bad = 0;
   const size_t first_valid = TJP_WIN - win_valid;
+  if (win_valid == TJP_WIN && n >= 65536u) {
+    /* A whole window in front and plenty to do: one table for bytes and markers alike, one look-up per symbol and no
+     * branch.  (Markers do not die out behind a stretch's first 32 KiB: a match copies them, and text with a period --
+     * read names, quality strings -- keeps copying what it copied before, so most of a stretch's symbols may be markers.) */
+    unsigned char *lut = (unsigned char *) malloc (256u + TJP_WIN);
+    if (lut) {
+      unsigned v;
+      for (v = 0; v < 256u; v++) lut[v] = (unsigned char) v;
+      memcpy (lut + 256, window, TJP_WIN);
+      for (; i + 4 <= n; i += 4) { out[i] = lut[sym[i]]; out[i + 1] = lut[sym[i + 1]]; out[i + 2] = lut[sym[i + 2]]; out[i + 3] = lut[sym[i + 3]]; }
+      for (; i < n; i++) out[i] = lut[sym[i]];
+      free (lut);
+      return 0;
+    }
+  }
 #if defined(__SSE2__)
   /* sixteen symbols at a time while they are all plain bytes (nearly everything behind a stretch's first 32 KiB) */
   for (; i + 16 <= n; i += 16) {
