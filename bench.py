@@ -225,7 +225,7 @@ def io_stages(tj, host, args, k, m, L):
             return b"\x1f\x8b\x08\x00" + b"\0" * 4 + b"\x00\xff" + body + tail
         return b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1) + body + tail
 
-    for key, blob, how in (("from_gzip", member(txt, False), "one gzip member: inflate on one thread, one window ahead of the parse"),
+    for key, blob, how in (("from_gzip", member(txt, False), "one gzip member: entered at block starts found by trial and inflated on all feeder threads (each stretch checked by the decoder in front of it), one window ahead of the parse"),
                            ("from_bgzf", b"".join(member(txt[i:i + 0xff00], True) for i in range(0, len(txt), 0xff00)) + member(b"", True),
                             "BGZF: members inflated side by side by the feeder threads")):
         gz = os.path.join(tmp, key + ".fq.gz")
