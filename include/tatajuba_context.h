@@ -29,7 +29,8 @@ extern "C" {
  * h->i[j].freq): distinct values with their summed weights, highest weight first */
 #ifndef TATAJUBA_AMD_HAVE_EMPFREQ
 typedef struct { int freq, idx; } empfreq_element;
-struct empfreq_struct { empfreq_element *i; int n, min, max; };    /* min / max: smallest and largest idx */
+struct empfreq_struct { empfreq_element *i; int n, min, max; };    /* min / max: smallest and largest idx (UNPINNED like the rest of empfreq: in
+                                                                    * biomcmc-lib they may be positions in `i` instead; tatajuba reads them in a debug print only) */
 typedef struct empfreq_struct *empfreq;
 #endif
 

@@ -2281,7 +2281,6 @@ void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
       lds_barrier ();
       PLSTAMP (6);
       // ---- copy-out: sorted slot i -> its place in the bucket's run
-#pragma unroll
       for (u32 r0 = 0; r0 < RR; r0 += 4) {
         if (r0 * PL_BLOCK >= n) break;
         u32 cb[4]; uint4 e[4]; u64 cw[4];
@@ -2307,8 +2306,7 @@ void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
     {
       const u64 *__restrict__ src = LG.log + ((u64) bn << TJ_LOGB_SHIFT);
       nn = LG.count[bn];
-#pragma unroll
-      for (u32 r = 0; r < RR; r++) w[r] = (src + r * PL_BLOCK)[tid];
+      for (u32 r = 0; r < RR; r++) w[r] = (src + r * PL_BLOCK)[tid];       /* (unrolled by the compiler with the loop's other copy: a pragma here only draws a warning) */
     }
     n = nn; b = bn;
   }
@@ -5745,6 +5743,36 @@ static long gx_block_cap (long max_count)
 { // what a block takes after an exchange whose fullest rank held max_count: a quarter more, in steps of 4096 records
   const long want = max_count + max_count / 4 + 1;
   return ((want + 4095) / 4096) * 4096;
+}
+
+// Test hook (not in the public header): the exchange's pack and unpack kernels on fabricated data -- what the ranks r > 0 of
+// a communicator would have sent -- on one GPU.  samples[r] / n[r]: rank r's kept records (host, 3 words each); every rank's
+// block is packed with gx_pack_kernel for a block of `cap` records and the blocks are unpacked as tjamd_allgather_histograms
+// unpacks what ncclAllGather delivers.  out: world * cap records (host); counts[r] = what rank r says it holds (n[r], also
+// when it exceeds cap: the caller's cue to agree on a larger block).  Returns the records unpacked (sum of min (n[r], cap)).
+extern "C" long tjamd_debug_exchange_pack_unpack (tjamd_counter *c, const u64 *const *samples, const long *n, int world, long cap, u64 *out, long *counts)
+{
+  if (!c || !samples || !n || world < 1 || cap < 1 || !out || !counts) return -set_err (TJAMD_ERR_ARG, "bad arguments");
+  if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
+  const long block_words = GX_HEADER / 8 + 3 * cap;
+  u64 *d_kept = nullptr, *d_recv = nullptr, *d_out = nullptr; long *d_counts = nullptr;
+  long total = 0, mx = 1;
+  for (int r = 0; r < world; r++) mx = std::max (mx, n[r]);
+  if (hipMalloc ((void **) &d_kept, (size_t) mx * 24) != hipSuccess || hipMalloc ((void **) &d_recv, (size_t) block_words * 8 * (size_t) world) != hipSuccess ||
+      hipMalloc ((void **) &d_out, (size_t) cap * world * 24) != hipSuccess || hipMalloc ((void **) &d_counts, (size_t) world * sizeof (long)) != hipSuccess)
+    return -set_err (TJAMD_ERR_HIP, "hipMalloc failed");
+  for (int r = 0; r < world; r++) {
+    if (n[r] && hipMemcpyAsync (d_kept, samples[r], (size_t) n[r] * 24, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "copy failed");
+    hipLaunchKernelGGL (gx_pack_kernel, dim3 (grid_for (3 * std::min (n[r], cap) + 1)), dim3 (256), 0, c->stream, (const u64 *) d_kept, n[r], cap, d_recv + (size_t) r * block_words);
+    if (hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "pack failed");
+    total += std::min (n[r], cap);
+  }
+  hipLaunchKernelGGL (gx_unpack_kernel, dim3 (grid_for (3 * cap + 1), (unsigned) std::min (world, 64)), dim3 (256), 0, c->stream, (const u64 *) d_recv, block_words, world, cap, d_out, d_counts);
+  if (hipMemcpyAsync (out, d_out, (size_t) total * 24, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipMemcpyAsync (counts, d_counts, (size_t) world * sizeof (long), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize (c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "unpack failed: %s", hipGetErrorString (hipGetLastError ()));
+  (void) hipFree (d_kept); (void) hipFree (d_recv); (void) hipFree (d_out); (void) hipFree (d_counts);
+  return total;
 }
 
 extern "C" long tjamd_allgather_histograms (tjamd_counter *c, tjamd_comm *m, const void **d_records, long *counts)

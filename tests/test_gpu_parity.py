@@ -1265,6 +1265,32 @@ def test_rccl_allgather_of_one_rank_and_block_size_protocol():
     small.close(); big.close()
 
 
+def test_exchange_pack_and_unpack_for_several_ranks_on_one_gpu():
+    """What tjamd_allgather_histograms does around its collective, for a communicator of five ranks, on one GPU: every
+    rank's kept records packed into a max-padded block (count in the header), the blocks unpacked back to back in rank
+    order -- offsets of the ranks r > 0 included, an empty rank, and a rank that holds more than the agreed block (its
+    count comes back whole, its records cut at the block: the caller's cue to settle on a larger block and go again)."""
+    import ctypes as C
+    L = tj.lib()
+    rng = np.random.default_rng(17)
+    cap = 4096
+    ns = [1500, 0, 4096, 6000, 7]
+    samples = [rng.integers(0, 1 << 63, size=(n, 3), dtype=np.uint64) for n in ns]
+    c = tj.Counter(10)
+    ptrs = (C.c_void_p * len(ns))(*[s.ctypes.data for s in samples])
+    n_arr = (C.c_long * len(ns))(*ns)
+    out = np.zeros((cap * len(ns), 3), np.uint64)
+    counts = (C.c_long * len(ns))()
+    L.tjamd_debug_exchange_pack_unpack.restype = C.c_long
+    L.tjamd_debug_exchange_pack_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_void_p]
+    tot = L.tjamd_debug_exchange_pack_unpack(c._h, ptrs, n_arr, len(ns), cap, out.ctypes.data, counts)
+    assert tot == sum(min(n, cap) for n in ns), L.tjamd_last_error()
+    assert list(counts) == ns                                  # rank 3 says 6000 > cap: the exchange would be repeated with a larger block
+    want = np.concatenate([s[:cap] for s in samples])
+    assert (out[:tot] == want).all()
+    c.close()
+
+
 def test_merge_samples_c_example(tmp_path):
     """examples/merge_samples.c: two samples, two counters, gather + merge + tract ids from plain C, no Python in the loop"""
     import subprocess
