@@ -4048,6 +4048,11 @@ struct tjamd_counter
   bool log_mode = true;       // k <= 12: the fast kernel writes a log and partition_log_kernel fills the buckets (TATAJUBA_AMD_SINK=fused: the kernel partitions by itself)
   bool log_next_clean[2] = {false, false};
   hipEvent_t ev_p1 = nullptr; // after the partition kernel of the last scan call
+  // a stream scanned in pieces runs scan, partition, scan, partition, ...: an event in front of every partition kernel but the
+  // last and one behind it, so that the scan's and the partition's times can be told apart (TJ_PIECE_EVENTS pieces; beyond: lumped)
+#define TJ_PIECE_EVENTS 64
+  hipEvent_t ev_pa[TJ_PIECE_EVENTS] = {}, ev_pb[TJ_PIECE_EVENTS] = {};
+  int n_piece_ev = 0;
   hipEvent_t ev_m0 = nullptr, ev_m1 = nullptr; bool merge_timed = false;   // around the kernels of the last tjamd_merge_samples
   bool part_timed = false;
   int fast_mode = 1;          // 1: scan_fast_kernel + the generic kernel on what it leaves; 0: generic kernel only; 2: fast kernel leaves everything (tests)
@@ -4166,6 +4171,7 @@ extern "C" void tjamd_counter_destroy (tjamd_counter *c)
   if (c->ev_s0) (void) hipEventDestroy (c->ev_s0);
   if (c->ev_s1) (void) hipEventDestroy (c->ev_s1);
   if (c->ev_p1) (void) hipEventDestroy (c->ev_p1);
+  for (int i = 0; i < TJ_PIECE_EVENTS; i++) { if (c->ev_pa[i]) (void) hipEventDestroy (c->ev_pa[i]); if (c->ev_pb[i]) (void) hipEventDestroy (c->ev_pb[i]); }
   if (c->ev_m0) (void) hipEventDestroy (c->ev_m0);
   if (c->ev_m1) (void) hipEventDestroy (c->ev_m1);
   if (c->ev_f0) (void) hipEventDestroy (c->ev_f0);
@@ -4510,10 +4516,18 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
 #undef TJ_LAUNCH_SCAN
   HIPCHK (hipGetLastError ());
   if (last) HIPCHK (hipEventRecord (c->ev_s1, c->stream));
+  if (first) c->n_piece_ev = 0;
+  const bool mid_events = use_log && !last && c->n_piece_ev < TJ_PIECE_EVENTS;
+  if (mid_events) {
+    const int i = c->n_piece_ev;
+    if (!c->ev_pa[i]) { HIPCHK (hipEventCreate (&c->ev_pa[i])); HIPCHK (hipEventCreate (&c->ev_pb[i])); }
+    HIPCHK (hipEventRecord (c->ev_pa[i], c->stream));
+  }
   if (use_log) {
     hipLaunchKernelGGL (partition_log_kernel, dim3 ((unsigned) (c->n_cu * PL_WG_PER_CU)), dim3 (PL_BLOCK), 0, c->stream, LG, BK, c->d_ctr, c->k);
     HIPCHK (hipGetLastError ());
   }
+  if (mid_events) { HIPCHK (hipEventRecord (c->ev_pb[c->n_piece_ev], c->stream)); c->n_piece_ev++; }
   if (last) { HIPCHK (hipEventRecord (c->ev_p1, c->stream)); c->part_timed = use_log; }
   c->scan_timed = true;
   c->last_scan_launches = first ? 1 : c->last_scan_launches + 1;
@@ -5061,6 +5075,8 @@ extern "C" double tjamd_last_scan_ms (tjamd_counter *c)
   if (!c || !c->scan_timed) return -1.0;
   float ms = 0.f;
   if (hipSetDevice (c->device) != hipSuccess || hipEventSynchronize (c->ev_s1) != hipSuccess || hipEventElapsedTime (&ms, c->ev_s0, c->ev_s1) != hipSuccess) return -1.0;
+  // (a stream scanned in pieces: the partition kernels between the scans are not the scan's time)
+  for (int i = 0; i < c->n_piece_ev; i++) { float p = 0.f; if (hipEventElapsedTime (&p, c->ev_pa[i], c->ev_pb[i]) == hipSuccess) ms -= p; }
   return (double) ms;
 }
 
@@ -5082,6 +5098,7 @@ extern "C" double tjamd_last_partition_ms (tjamd_counter *c)
   if (!c->part_timed) return 0.0;
   float ms = 0.f;
   if (hipSetDevice (c->device) != hipSuccess || hipEventSynchronize (c->ev_p1) != hipSuccess || hipEventElapsedTime (&ms, c->ev_s1, c->ev_p1) != hipSuccess) return -1.0;
+  for (int i = 0; i < c->n_piece_ev; i++) { float p = 0.f; if (hipEventElapsedTime (&p, c->ev_pa[i], c->ev_pb[i]) == hipSuccess) ms += p; }   // (the pieces before the last)
   return (double) ms;
 }
 
