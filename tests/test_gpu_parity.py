@@ -376,6 +376,20 @@ def test_streams_with_no_calls_match_the_oracle(k, m):
     assert n > 10000
     st, kept = check_finalise([s], k, m, 1, 3)
     assert st == 0 and kept > 100
+    if os.environ.get("TATAJUBA_AMD_FAST", "1") == "1":
+        # isolated no-calls alone: the fast kernel keeps (nearly) every tile -- they are classified a second time, not handed over
+        import ctypes as C
+        s2 = tj.synth_stream(60000, 150, 200000).copy()
+        s2[reads[:2400] * 151 + rng.integers(0, 150, 2400)] = ord("N")
+        c = tj.Counter(k)
+        c.scan_host(s2, m)
+        L = tj.lib()
+        L.tjamd_debug_slow_tiles.restype = C.c_long; L.tjamd_debug_slow_tiles.argtypes = [C.c_void_p]
+        n_tiles = (s2.size + 16287) // 16288
+        assert 0 <= L.tjamd_debug_slow_tiles(c._h) <= n_tiles // 20, (L.tjamd_debug_slow_tiles(c._h), n_tiles)
+        got = c.download_raw()
+        assert (rec_sorted(got) == rec_sorted(as_records(oracle_raw(s2, k, m).elems()))).all()
+        c.close()
 
 
 @pytest.mark.parametrize("mode", ["plan", "noplan", "cap", "plan+order", "cap+order", "nofuse"])

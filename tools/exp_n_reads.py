@@ -20,5 +20,6 @@ for frac in fracs:
     for it in range(5):
         c.reset(); c.scan_device(d.data_ptr(), s.size, 3); c.sync()
         best = min(best, c.last_scan_ms())
-    print(f"reads with an N: {frac * 100:5.2f} %   scan {best:.3f} ms   raw {c.raw_count()}")
+    L = tj.lib(); L.tjamd_debug_slow_tiles.restype = __import__("ctypes").c_long; L.tjamd_debug_slow_tiles.argtypes = [__import__("ctypes").c_void_p]
+    print(f"reads with an N: {frac * 100:5.2f} %   scan {best:.3f} ms   raw {c.raw_count()}   tiles left to the generic kernel: {L.tjamd_debug_slow_tiles(c._h)} of {(s.size + 16287) // 16288}")
     c.close()
