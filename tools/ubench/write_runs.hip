@@ -18,6 +18,11 @@ __global__ __launch_bounds__ (512) void write_runs (u64 *pool, u64 region_words,
       pool[(u64) b * region_words + (u64) p * STRIDE + o] = ((u64) p << 32) | (u32) i | 1u;
     }
 }
+__global__ __launch_bounds__ (512) void write_linear (u64 *pool, u32 passes)
+{
+  for (u32 p = blockIdx.x; p < passes; p += gridDim.x)
+    for (int i = threadIdx.x; i < 4096; i += 512) pool[(u64) p * 4096 + i] = ((u64) p << 32) | (u32) i | 1u;
+}
 template <int R, int STRIDE>
 static void run (const char *what, u64 *pool, u64 region_words, u64 records)
 {
@@ -47,5 +52,19 @@ int main ()
   run<64, 64> ("runs of 64", pool, region_words, records);
   run<15, 15> ("runs of 15, back to back", pool, region_words, records);
   run<8, 8> ("runs of 8 = half lines", pool, region_words, records);
+  run<128, 128> ("runs of 128", pool, region_words, records);
+  run<256, 256> ("runs of 256 (2 KB)", pool, region_words, records);
+  {                                                     /* for reference: the same bytes written in a line (every workgroup 32 KB at a time) */
+    hipEvent_t e0, e1; hipEventCreate (&e0); hipEventCreate (&e1);
+    float best = 1e9f;
+    for (int it = 0; it < 5; it++) {
+      hipEventRecord (e0);
+      write_linear<<<768, 512>>> (pool, (u32) (records / 4096));
+      hipEventRecord (e1); hipEventSynchronize (e1);
+      float ms; hipEventElapsedTime (&ms, e0, e1);
+      if (ms < best) best = ms;
+    }
+    printf ("%-34s               : %.3f ms for %.0f M records = %.0f GB/s of records\n", "in a line, 32 KB per workgroup", best, records / 4096 * 4096 / 1e6, records / 4096 * 4096.0 * 8 / best / 1e6);
+  }
   return 0;
 }
