@@ -607,27 +607,41 @@ typedef struct
   int j, n;
   size_t nominal_bit, round_end_bit;
   size_t start_bit;             /* (size_t) -1: no block start found */
-  size_t *starts;               /* all stretches' start_bit, read behind the barrier */
-  pthread_barrier_t *bar;
+  size_t *starts;               /* all stretches' start_bit, complete when the decoding begins */
   int rc;
 } tjz_stretch_job;
 
 static void *
-tjz_stretch_run (void *arg)
+tjz_stretch_find (void *arg)
 {
   tjz_stretch_job *k = (tjz_stretch_job *) arg;
-  tjz_source *s = k->s;
-  size_t stop;
-  int i;
-  if (k->j > 0) k->start_bit = tjp_find_block (s->z, s->zn, k->nominal_bit, k->nominal_bit + s->seg_bytes * 4);   /* (half a stretch) */
+  if (k->j > 0) k->start_bit = tjp_find_block (k->s->z, k->s->zn, k->nominal_bit, k->nominal_bit + k->s->seg_bytes * 4);   /* (half a stretch) */
   k->starts[k->j] = k->start_bit;
-  pthread_barrier_wait (k->bar);
+  return NULL;
+}
+
+static void *
+tjz_stretch_decode (void *arg)
+{
+  tjz_stretch_job *k = (tjz_stretch_job *) arg;
+  size_t stop = k->round_end_bit;
+  int i;
   k->rc = -2;
   if (k->start_bit == (size_t) -1) return NULL;
-  stop = k->round_end_bit;
   for (i = k->j + 1; i < k->n; i++) if (k->starts[i] != (size_t) -1) { stop = k->starts[i]; break; }
-  k->rc = tjp_decode (s->z, s->zn, k->start_bit, stop, &s->seg[k->j]);
+  k->rc = tjp_decode (k->s->z, k->s->zn, k->start_bit, stop, &k->s->seg[k->j]);
   return NULL;
+}
+
+/* jobs 1 .. n - 1 on threads of their own, job 0 here; a thread that cannot be had: its job here as well */
+static void
+tjz_run_all (void *(*fn) (void *), tjz_stretch_job *job, int n)
+{
+  pthread_t th[TJF_MAX_THREADS];
+  int started[TJF_MAX_THREADS], j;
+  for (j = 1; j < n; j++) started[j] = pthread_create (&th[j], NULL, fn, &job[j]) == 0;
+  (void) fn (&job[0]);
+  for (j = 1; j < n; j++) { if (started[j]) pthread_join (th[j], NULL); else (void) fn (&job[j]); }
 }
 
 typedef struct { const unsigned short *sym; size_t n; const unsigned char *win; size_t win_valid; unsigned char *out; int rc; unsigned crc; } tjz_resolve_job;
@@ -658,30 +672,25 @@ tjz_round (tjz_source *s, unsigned char *direct, size_t direct_room, size_t *dir
   size_t starts[TJF_MAX_THREADS];
   unsigned char (*win)[32768] = NULL;
   size_t win_valid[TJF_MAX_THREADS + 1];
-  pthread_barrier_t bar;
   const size_t base = s->pbit >> 3, end_bit = s->zn * 8;
   size_t total = 0, off;
   int n = s->n_threads, j, nc = 0, rc = 0, n_direct = 0;
   if (n > TJF_MAX_THREADS) n = TJF_MAX_THREADS;
   while (n > 1 && base + (size_t) (n - 1) * s->seg_bytes + 65536 >= s->zn) n--;     /* stretches that would begin at the file's end */
-  if (pthread_barrier_init (&bar, NULL, (unsigned) n)) return -1;
   for (j = 0; j < n; j++) {
-    job[j].s = s; job[j].j = j; job[j].n = n; job[j].starts = starts; job[j].bar = &bar; job[j].rc = -2;
+    job[j].s = s; job[j].j = j; job[j].n = n; job[j].starts = starts; job[j].rc = -2;
     job[j].nominal_bit = (base + (size_t) j * s->seg_bytes) * 8;
     job[j].round_end_bit = (base + (size_t) n * s->seg_bytes) * 8;
     if (job[j].round_end_bit > end_bit) job[j].round_end_bit = end_bit;
     job[j].start_bit = j ? (size_t) -1 : s->pbit;
-    started[j] = 0;
   }
-  for (j = 1; j < n; j++) {
-    if (pthread_create (&th[j], NULL, tjz_stretch_run, &job[j]) == 0) started[j] = 1;
-    else { pthread_barrier_destroy (&bar); while (--j >= 1) if (started[j]) pthread_cancel (th[j]); return -1; }   /* (no thread: give up on this file) */
+  {
+    /* first every stretch's start, then -- each one's end being the next one's start -- the decoding */
+    const double t_ = tjf_now ();
+    tjz_run_all (tjz_stretch_find, job, n);
+    tjz_run_all (tjz_stretch_decode, job, n);
+    s->t_decode += tjf_now () - t_;
   }
-  { const double t_ = tjf_now ();
-  tjz_stretch_run (&job[0]);
-  for (j = 1; j < n; j++) if (started[j]) pthread_join (th[j], NULL);
-  s->t_decode += tjf_now () - t_; }
-  pthread_barrier_destroy (&bar);
   s->par_rounds++;
   /* the chain of stretches each of which was reached by the decoder of the one before */
   *direct_got = 0;

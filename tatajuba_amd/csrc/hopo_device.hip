@@ -1502,7 +1502,9 @@ struct LogSink
 
   __device__ __forceinline__ u64 block_addr (u32 id) const
   {
-    if (id >= G.n_blocks) { ctr->overflow = 1u; return scratch; }     // (cannot happen: the log is sized for a tract every m' bytes)
+    // (cannot happen: the log is sized for a tract every m' bytes.  If it did: the flag makes the scan fail; until then the
+    // records go to block 0, inside the log -- the scratch words are 64 per workgroup, not a block)
+    if (id >= G.n_blocks) { ctr->overflow = 1u; return (u64) (size_t) G.log; }
     return (u64) (size_t) G.log + (((u64) id << TJ_LOGB_SHIFT) << 3);
   }
   __device__ __forceinline__ void start ()
