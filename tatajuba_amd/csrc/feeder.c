@@ -930,8 +930,8 @@ static void *tjz_fill_thread (void *arg) { tjz_fill_job *f = (tjz_fill_job *) ar
 
 /* The buffers of a gzip file -- two views, the round's bytes, the stretches' symbols: some 300 MB -- are kept for the next
  * file instead of going back to the allocator: a sample is read as several files (R1, R2, and the caller runs one thread
- * per sample), and first-touch page faults on fresh buffers were a quarter of a 70 MB file's time.  Up to TJZ_KEEP sets. */
-#define TJZ_KEEP 8
+ * per sample), and first-touch page faults on fresh buffers were a quarter of a 70 MB file's time.  Up to TJZ_KEEP sets (what more files at once use is freed when they are done). */
+#define TJZ_KEEP 4
 typedef struct { int used; unsigned char *view[2]; size_t view_cap[2], head[2]; unsigned char *pout; size_t pout_cap; tjp_segment seg[TJF_MAX_THREADS]; } tjz_buffers;
 static tjz_buffers tjz_kept[TJZ_KEEP];
 static pthread_mutex_t tjz_kept_lock = PTHREAD_MUTEX_INITIALIZER;

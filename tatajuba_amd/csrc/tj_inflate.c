@@ -651,6 +651,7 @@ tjp_decode (const unsigned char *z, size_t zn, size_t start_bit, size_t stop_bit
     if (p >= stop_bit) { rc = 0; break; }               /* at a block boundary at or behind the target */
     if (n + 65536u + 258u + 1024u > cap) {               /* room for a stored block or a long stretch of coded output */
       unsigned short *nb;
+      if (cap >= ((size_t) 1 << 29)) break;               /* (a stretch that will not end: give up, what was decoded so far stands) */
       cap *= 2;
       nb = (unsigned short *) realloc (buf, (TJP_WIN + cap) * sizeof (unsigned short));
       if (!nb) break;
@@ -671,7 +672,7 @@ tjp_decode (const unsigned char *z, size_t zn, size_t start_bit, size_t stop_bit
         size_t q = p, k = n;
         const int r = tjp_block (z, zn, &q, t, buf + TJP_WIN, &k, cap);
         if (r == 0) { p = q; n = k; break; }
-        if (r == -3 && cap < ((size_t) 1 << 32)) {
+        if (r == -3 && cap < ((size_t) 1 << 28)) {       /* (a block of more than 256 M bytes: not for this decoder -- the caller's single one streams it) */
           unsigned short *nb;
           cap *= 2;
           nb = (unsigned short *) realloc (buf, (TJP_WIN + cap) * sizeof (unsigned short));
