@@ -19,7 +19,8 @@
  * A plain file is mapped whole and the windows walk over it.  A gzip file (the usual input: the reference opens
  * everything through zlib, src/hopo_counter.c:142) is inflated a VIEW at a time by a producer thread that runs one
  * view ahead of the parse: BGZF files (bgzip: independent members that state their compressed and uncompressed
- * sizes) by all threads at once, any other gzip stream by one thread (deflate cannot be entered in the middle).  A
+ * sizes) by all threads at once, any other gzip member by all threads as well -- entered at block starts found by trial,
+ * every stretch checked by the decoder of the stretch in front (tjz_round) -- or by one thread when that finds nothing.  A
  * view ends wherever the inflated bytes happened to end; the last reader of a view gives back the record it was in
  * when it touched the end (tjr_at_end), and those bytes open the next view.
  *
