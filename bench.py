@@ -484,7 +484,7 @@ def main():
     # HBM bytes per launch from the PMC passes of the same command (tools/pmc_traffic.py -> profiles/; rocprofv3 cannot
     # run inside the timed process), only when they were taken on this workload
     uses_log = c.uses_log()
-    scan_kernel = "scan_fast_kernel<1, true>" if uses_log else "scan_fast_kernel<%d, false>" % (1 if k <= 12 else (2 if k <= 28 else 4))
+    scan_kernel = "scan_fast_kernel<%d, %s>" % (1 if k <= 12 else (2 if k <= 28 else 4), "true" if uses_log else "false")
     traffic, traffic_src = None, None
     import glob
     for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):     # the latest round's passes first
@@ -534,7 +534,7 @@ def main():
         out["config"]["rccl_ranks"] = comm.count if comm is not None else None
         out["config"]["control_plane"] = "torch.distributed over gloo (rendezvous, barrier, max over ranks); data path: the library's RCCL communicator"
     if uses_log:
-        # k <= 12: the scan kernel appends its records to a linear log, partition_log_kernel distributes the log over the hash
+        # k <= 28: the scan kernel appends its records to a linear log, partition_log_kernel distributes the log over the hash
         # buckets (its algorithmic bytes: every record read once and written once)
         part_bytes = 2.0 * wbytes * raw
         out["stages"]["partition"] = {"ms": part_avg, "kernel": "partition_log_kernel", "algorithmic_bytes": part_bytes,

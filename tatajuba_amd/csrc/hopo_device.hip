@@ -1491,11 +1491,15 @@ struct LogLds
   u32 n;                                // records appended by this workgroup
 };
 
+// W: words per record (1: k <= 12, 2: k <= 28).  A block is TJ_LOGB words whatever W is: 8192 one-word or 4096 two-word records.
+template <int W>
 struct LogSink
 {
+  static_assert (W == 1 || W == 2, "the log holds one-word and two-word records");
   static constexpr int S = 0x7FFFFFF0;                  // (no buffer to fill up: every tile "fits")
+  static constexpr u32 RS = TJ_LOGB_SHIFT - (W == 2 ? 1 : 0), RB = 1u << RS;     // records per block
   LogLds &L;
-  LogSpace G; DevCounters *ctr;
+  LogSpace G; DevCounters *ctr; int k;
   u32 bound;
   u32 upto, pend, pend_id;                              // thread 0: last block index with an address in L.blk; a reservation on its way
   u64 scratch;                                          // where lanes without a record write (byte address, 64 words per workgroup)
@@ -1526,29 +1530,43 @@ struct LogSink
     if (threadIdx.x == 0 && pend) {
       upto++;
       const u32 slot = upto & 3u, old = L.id[slot];
-      if (old < G.n_blocks) G.count[old] = TJ_LOGB;
+      if (old < G.n_blocks) G.count[old] = RB;
       L.id[slot] = pend_id; L.blk[slot] = block_addr (pend_id);
       pend = 0;
     }
   }
-  // `n`: the workgroup's count, read while nobody appends
+  // `n`: the workgroup's count, read while nobody appends.  (A tile brings at most FK_MAXCAND = 4096 records, a block
+  // holds at least as many: at most one new block per tile, asked for TJ_LOG_AHEAD records -- two tiles -- ahead, so that the
+  // tile after the asking one, which picks the address up at its top, is the first that can need it; the ring slot it
+  // takes held block j - 4 while the appends are at j - 3 or later.)
   __device__ __forceinline__ void tile_top (u32 n)
   {
-    if (threadIdx.x == 0 && !pend && ((n + TJ_LOG_AHEAD) >> TJ_LOGB_SHIFT) > upto) { pend_id = atomicAdd (G.next, 1u); pend = 1u; }
+    if (threadIdx.x == 0 && !pend && ((n + TJ_LOG_AHEAD) >> RS) > upto) { pend_id = atomicAdd (G.next, 1u); pend = 1u; }
   }
   __device__ __forceinline__ void reserve1 (u32) {}
   __device__ __forceinline__ u32 count_addr () const { return (u32) (size_t) (lptr_t) &L.n; }
+  __device__ __forceinline__ u64 place (u32 at) const { return L.blk[(at >> RS) & 3u] + (8ull * W) * (at & (RB - 1u)); }
   __device__ __forceinline__ void store1 (u32 at, u32 lo, u32 hi)
   {
     typedef __attribute__((address_space(1))) u64 *gwords_t;
-    *(gwords_t) (L.blk[(at >> TJ_LOGB_SHIFT) & 3u] + 8ull * (at & (TJ_LOGB - 1u))) = ((u64) hi << 32) | lo;
+    *(gwords_t) place (at) = ((u64) hi << 32) | lo;
   }
   // branch-free: a lane without a record writes to the workgroup's scratch words
   __device__ __forceinline__ void store1ok (bool ok, u32 at, u32 lo, u32 hi, u32 lane)
   {
     typedef __attribute__((address_space(1))) u64 *gwords_t;
-    const u64 a = L.blk[(at >> TJ_LOGB_SHIFT) & 3u] + 8ull * (at & (TJ_LOGB - 1u));
+    const u64 a = place (at);
     *(gwords_t) (ok ? a : scratch + 8ull * lane) = ((u64) hi << 32) | lo;
+  }
+  // a record from its fields (the two-word kernel's phase 3)
+  __device__ __forceinline__ void store_fields (u32 at, u64 c0, u64 c1, u32 base, u32 len10, u32 flag)
+  {
+    typedef __attribute__((address_space(1))) u64 *gwords_t;
+    u64 w[W];
+    pack_raw<W> (c0, c1, base, len10, flag, k, w);
+    gwords_t q = (gwords_t) place (at);
+#pragma unroll
+    for (int j = 0; j < W; j++) q[j] = w[j];
   }
   __device__ __forceinline__ void finish ()
   {
@@ -1558,7 +1576,7 @@ struct LogSink
       const u32 n = L.n;
       for (u32 j = (upto >= 3u ? upto - 3u : 0u); j <= upto; j++) {
         const u32 id = L.id[j & 3u];
-        if (id < G.n_blocks) G.count[id] = (n > (j << TJ_LOGB_SHIFT)) ? min (n - (j << TJ_LOGB_SHIFT), TJ_LOGB) : 0u;
+        if (id < G.n_blocks) G.count[id] = (n > (j << RS)) ? min (n - (j << RS), RB) : 0u;
       }
     }
   }
@@ -1702,12 +1720,12 @@ __global__ __launch_bounds__ (FK_BLOCK, FK_BLOCK * (LOG ? FK_LOG_WG_PER_CU : FK_
 void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_ftiles, int k, int mprime,
                        Buckets BK, DevCounters *ctr, u32 *__restrict__ slow_list, int par, int all_slow, LogSpace LG)
 {
-  static_assert (!LOG || W == 1, "the record log holds one-word records");
+  static_assert (!LOG || W <= 2, "the record log holds one-word and two-word records");
   __shared__ FastLds T;
   __shared__ uint4 raw[FK_WIN / 16];
   __shared__ std::conditional_t<LOG, LogLds, StageLds<W, true>> SL;
   auto make_sink = [&] () {
-    if constexpr (LOG) return LogSink {SL, LG, ctr, 0u, 0u, 0u, 0u, 0ull};
+    if constexpr (LOG) return LogSink<W> {SL, LG, ctr, k, 0u, 0u, 0u, 0u, 0ull};
     else return StageSink<W, FK_BLOCK, true> {SL, BK, ctr, k, 0u, 0u, 0u};
   };
   auto sink = make_sink ();
@@ -2192,21 +2210,25 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
 #ifndef PL_WG_PER_CU
 #define PL_WG_PER_CU 2
 #endif
+template <int W>
 __global__ __launch_bounds__ (PL_BLOCK, PL_BLOCK * PL_WG_PER_CU / 256)
 void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
 {
-  // One log block (TJ_LOGB records, 16 per thread) per pass, the records in registers from the load to their place in the
-  // sorted buffer: count per bucket (LDS atomics) -- prefix, one reservation per bucket, where the runs go (the owners, as
-  // in StageSink::partition_pass) -- every record straight to its sorted slot in LDS (its rank: an LDS atomic on the
-  // bucket's running position) -- the sorted buffer out in runs, coalesced.  Four barriers per 8192 records; two
-  // workgroups per CU cover each other's waits.  What bounds it is the memory system: 0.48 GB read in a line, 0.48 GB
-  // written in runs of 32 records to 256 places (tools/ubench/write_runs.hip: that write pattern alone takes 0.16 ms);
-  // loading the next block's records while this one is sorted and written changed nothing (tried, with 32 more registers).
-  typedef StageLds<1, 2> Lds;
+  // One log block (TJ_LOGB words: 8192 one-word or 4096 two-word records, 16 words per thread) per pass, the records in
+  // registers from the load to their place in the sorted buffer: count per bucket (LDS atomics) -- prefix, one
+  // reservation per bucket, where the runs go (the owners, as in StageSink::partition_pass) -- every record straight to
+  // its sorted slot in LDS (its rank: an LDS atomic on the bucket's running position) -- the sorted buffer out in runs,
+  // coalesced.  Four barriers per block; two workgroups per CU cover each other's waits.  What bounds it is the memory
+  // system: for the 10 M-read sample's one-word records 0.48 GB read in a line, 0.48 GB written in runs of 32 records to
+  // 256 places (tools/ubench/write_runs.hip: that write pattern alone takes 0.16 ms); loading the next block's records
+  // while this one is sorted and written changed nothing (tried, with 32 more registers).
+  static_assert (W == 1 || W == 2, "the log holds one-word and two-word records");
+  typedef StageLds<W, 2> Lds;
   __shared__ Lds L;
-  static_assert (Lds::S == (int) TJ_LOGB, "one pass per log block");
-  constexpr u32 RR = TJ_LOGB / PL_BLOCK;
-  static_assert (RR == 16, "bins are kept four to a register");
+  constexpr u32 RB = TJ_LOGB / W;                        // records per block
+  static_assert (Lds::S == (int) RB && Lds::WS == W, "one pass per log block");
+  constexpr u32 RR = RB / PL_BLOCK;                      // records per thread
+  static_assert (RR % 4 == 0, "bins are kept four to a register");
   const u32 tid = threadIdx.x, lane = tid & 63u;
   const u32 wave = (u32) __builtin_amdgcn_readfirstlane ((int) (tid >> 6));
   if (tid < TJ_P) L.hist[tid] = 0;
@@ -2219,8 +2241,8 @@ void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
   // (blocks in turn, static: a shared work counter would be one more address that every workgroup of the grid adds to)
   u32 b = blockIdx.x;
   if (b >= n_blocks) return;
-  u64 w[RR];
-  u32 n = min (LG.count[b], TJ_LOGB), nn = 0;
+  u64 w[RR][W];
+  u32 n = min (LG.count[b], RB), nn = 0;
   // a block's records, the part of it that was written: whole waves skip what lies behind the block's count (every scanning
   // workgroup leaves one block partly filled and one empty: a tenth of all blocks on the 10 M-read sample, nearly all of
   // them on a sparse one)
@@ -2228,27 +2250,38 @@ void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
     const u64 *__restrict__ src = LG.log + ((u64) blk << TJ_LOGB_SHIFT);
     const u32 w0 = tid & ~63u;                            // (the wave's first thread: uniform)
 #pragma unroll
-    for (u32 r = 0; r < RR; r++) { w[r] = 0; if (w0 + r * PL_BLOCK < cnt) w[r] = (src + r * PL_BLOCK)[tid]; }
+    for (u32 r = 0; r < RR; r++) {
+#pragma unroll
+      for (int j = 0; j < W; j++) w[r][j] = 0;
+      if (w0 + r * PL_BLOCK < cnt) {
+        if constexpr (W == 1) w[r][0] = (src + r * PL_BLOCK)[tid];
+        else { const ulonglong2 v = reinterpret_cast<const ulonglong2 *> (src + 2u * r * PL_BLOCK)[tid]; w[r][0] = v.x; w[r][1] = v.y; }
+      }
+    }
+  };
+  auto bucket_of = [&] (const u64 *rec) -> u32 {
+    if constexpr (W == 1) return bucket_of_rec1 ((u32) rec[0], (u32) (rec[0] >> 32));
+    else { u64 c0, c1; u32 base, len10, flag; unpack_raw<W> (rec, k, c0, c1, base, len10, flag); return bucket_of_key (c0, c1, base, len10); }
   };
   load_block (b, n);
   while (true) {
     const u32 bn = b + gridDim.x;
     const bool more = bn < n_blocks;                      // (uniform)
-    if (more) nn = min (LG.count[bn], TJ_LOGB);           // (asked for now, looked at when this block is done)
+    if (more) nn = min (LG.count[bn], RB);                // (asked for now, looked at when this block is done)
     PLSTAMP (0);
     u32 tq = tid;
     asm volatile ("" : "+v"(tq));                         // (opaque: what the compiler can derive from tid alone it hoists out of the loop -- sixteen 64-bit offsets 8 i took 32 registers and went to scratch)
-    u32 pk[RR / 4] = {0, 0, 0, 0};
+    u32 pk[RR / 4];
+#pragma unroll
+    for (u32 r = 0; r < RR / 4; r++) pk[r] = 0;
     if (n) {
       // ---- records per bucket
 #pragma unroll
       for (u32 r = 0; r < RR; r++) {
-        const u32 bin = bucket_of_rec1 ((u32) w[r], (u32) (w[r] >> 32));
+        const u32 bin = bucket_of (w[r]);
         pk[r >> 2] |= bin << (8u * (r & 3u));
         if (tid + r * PL_BLOCK < n) atomicAdd (&L.hist[bin], 1u);
       }
-    }
-    if (n) {
       PLSTAMP (1);
       lds_barrier ();
       PLSTAMP (2);
@@ -2264,14 +2297,14 @@ void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
         if (cnt) {
           const u32 p0 = atomicAdd (&BK.cursors[tid * TJ_CSTRIDE], cnt);
           const u32 ch = (u32) TJ_CH0 << BK.ch_shift;
-          bucket_claim_ahead_range (BK, tid, p0, cnt, ctr);   // (a run of up to TJ_LOGB records may hold more than one chunk's first record)
+          bucket_claim_ahead_range (BK, tid, p0, cnt, ctr);   // (a run of up to a block's records may hold more than one chunk's first record)
           const u32 j0 = chunk_of_pos (BK, p0), j1 = chunk_of_pos (BK, p0 + cnt - 1);
           if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (BK, tid, j0, true, ctr); }
-          if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch))) - 8ull * off;
+          if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch)) * W) - (8ull * W) * off;
           if (j1 != j0) {                                 // the run crosses into the next chunk (chunks are longer than a log block: at most once)
             thr = off + ((j0 + 1u) * ch - p0);
             cur_j = j0 + 1u; cur_chunk = bucket_chunk_id (BK, tid, j0 + 1u, true, ctr);
-            if (cur_chunk != TJ_NOCHUNK) a2 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch)) - 8ull * thr;
+            if (cur_chunk != TJ_NOCHUNK) a2 = (u64) (size_t) (BK.pool + ((u64) cur_chunk * ch) * W) - (8ull * W) * thr;
           }
         }
         reinterpret_cast<uint4 *> (L.gbase)[tid] = make_uint4 ((u32) a1, (u32) (a1 >> 32) | (thr << 16), (u32) a2, (u32) (a2 >> 32));
@@ -2286,7 +2319,8 @@ void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
         if (tid + r * PL_BLOCK < n) {
           const u32 bin = (pk[r >> 2] >> (8u * (r & 3u))) & 255u;
           const u32 d = atomicAdd (&L.offs[bin], 1u);
-          L.rec[d] = w[r];
+#pragma unroll
+          for (int j = 0; j < W; j++) L.rec[d * W + j] = w[r][j];
           L.bin[d] = (unsigned char) bin;
         }
       PLSTAMP (5);
@@ -2295,18 +2329,24 @@ void partition_log_kernel (LogSpace LG, Buckets BK, DevCounters *ctr, int k)
       // ---- copy-out: sorted slot i -> its place in the bucket's run
       for (u32 r0 = 0; r0 < RR; r0 += 4) {
         if (r0 * PL_BLOCK >= n) break;
-        u32 cb[4]; uint4 e[4]; u64 cw[4];
+        u32 cb[4]; uint4 e[4]; u64 cw[4][W];
 #pragma unroll
         for (u32 h = 0; h < 4; h++) cb[h] = L.bin[tq + (r0 + h) * PL_BLOCK];
 #pragma unroll
-        for (u32 h = 0; h < 4; h++) { e[h] = reinterpret_cast<const uint4 *> (L.gbase)[cb[h]]; cw[h] = L.rec[tq + (r0 + h) * PL_BLOCK]; }
+        for (u32 h = 0; h < 4; h++) {
+          e[h] = reinterpret_cast<const uint4 *> (L.gbase)[cb[h]];
+#pragma unroll
+          for (int j = 0; j < W; j++) cw[h][j] = L.rec[(tq + (r0 + h) * PL_BLOCK) * W + j];
+        }
 #pragma unroll
         for (u32 h = 0; h < 4; h++) {
           const u32 i = tq + (r0 + h) * PL_BLOCK;
           const u64 a = (i < (e[h].y >> 16)) ? (((u64) (e[h].y & 0xFFFFu) << 32) | e[h].x) : (((u64) e[h].w << 32) | e[h].z);
           if (i < n && a != 0ull) {
             typedef __attribute__((address_space(1))) u64 *gwords_t;
-            *(gwords_t) (a + (u64) (8u * i)) = cw[h];
+            gwords_t q = (gwords_t) (a + (u64) (8u * W * i));
+#pragma unroll
+            for (int j = 0; j < W; j++) q[j] = cw[h][j];
           }
         }
       }
@@ -4053,7 +4093,8 @@ struct tjamd_counter
   u32 *d_cursors = nullptr, *h_cursors = nullptr;     // [TJ_P] records per bucket, then [TJ_P] = next free chunk
   DevBuf pool, table, stage, fix, loc, prefix, rawlist, slow;
   DevBuf log, logmeta;        // the record log of scan_fast_kernel<1, true> and its block counters (2 words: blocks handed out, by launch parity; then a count per block)
-  bool log_mode = true;       // k <= 12: the fast kernel writes a log and partition_log_kernel fills the buckets (TATAJUBA_AMD_SINK=fused: the kernel partitions by itself)
+  int log_mode = 1;           // widest record (words) that goes through the record log and partition_log_kernel: 1 = k <= 12 (default), 2 = k <= 28 as well
+                              // (TATAJUBA_AMD_SINK=log), 0 = none, the scan kernels partition by themselves (TATAJUBA_AMD_SINK=fused)
   bool log_next_clean[2] = {false, false};
   hipEvent_t ev_p1 = nullptr; // after the partition kernel of the last scan call
   // a stream scanned in pieces runs scan, partition, scan, partition, ...: an event in front of every partition kernel but the
@@ -4135,7 +4176,8 @@ extern "C" tjamd_counter *tjamd_counter_create (int device, int kmer_size)
   const char *pc = getenv ("TATAJUBA_AMD_SCAN_PIECE");
   if (pc && atol (pc) >= 4096) c->piece_target = (size_t) atol (pc);
   const char *sk = getenv ("TATAJUBA_AMD_SINK");          // "fused": scan_fast_kernel<1> partitions its records itself (rounds 1-3); default: record log + partition_log_kernel
-  if (sk && !strcmp (sk, "fused")) c->log_mode = false;
+  if (sk && !strcmp (sk, "fused")) c->log_mode = 0;
+  if (sk && !strcmp (sk, "log")) c->log_mode = 2;
   const char *fm = getenv ("TATAJUBA_AMD_FAST");          // test hook: 0 = generic scan kernel only, 2 = fast kernel hands every tile over
   if (fm && atoi (fm) >= 0 && atoi (fm) <= 2) c->fast_mode = atoi (fm);
   const char *sl = getenv ("TATAJUBA_AMD_BUCKET_SLACK");
@@ -4481,12 +4523,12 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
   const bool use_fast = c->fast_mode && n_bytes < ((size_t) 1 << 31) - (1u << 20);
   // one-word records (k <= 12): the fast kernel appends to a log sized for the worst case (a tract every m' bytes; every
   // workgroup leaves at most two blocks partly filled), partition_log_kernel distributes it over the buckets
-  const bool use_log = use_fast && c->W == 1 && c->log_mode;
+  const bool use_log = use_fast && c->W <= c->log_mode;
   LogSpace LG = {nullptr, nullptr, nullptr, 0u};
   const int fgrid_log = (int) std::min<long> (n_ftiles, (long) c->n_cu * FK_LOG_WG_PER_CU);
   if (use_log) {
     // (a workgroup with n records has taken at most n / TJ_LOGB + 3 blocks: the one being filled and up to two ahead of it)
-    const u64 n_blocks = (bound >> TJ_LOGB_SHIFT) + 3ull * (u64) fgrid_log + 8ull;
+    const u64 n_blocks = ((bound * (u64) c->W) >> TJ_LOGB_SHIFT) + 3ull * (u64) fgrid_log + 8ull;      // (a block is TJ_LOGB words: TJ_LOGB / W records)
     rc = ensure (c->log, (size_t) (((n_blocks << TJ_LOGB_SHIFT) + 64ull * (u64) fgrid_log) * 8ull), c->stream);
     if (!rc && (size_t) (n_blocks + 2) * 4 > c->logmeta.cap) {
       rc = ensure (c->logmeta, (size_t) (n_blocks + 2) * 4 * 2, c->stream);
@@ -4502,8 +4544,8 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
 #define TJ_LAUNCH_SCAN(WW) do { \
     if (use_fast) { \
       /* the fast kernel takes every tile it can vouch for and lists the others; the generic kernel then works through the list */ \
-      if (WW == 1 && use_log) \
-        hipLaunchKernelGGL ((scan_fast_kernel<1, true>), dim3 (fgrid_log), dim3 (FK_BLOCK), 0, c->stream, seq, (long) n_bytes, n_ftiles, c->k, mprime, BK, c->d_ctr, \
+      if (WW <= 2 && use_log) \
+        hipLaunchKernelGGL ((scan_fast_kernel<(WW <= 2 ? WW : 1), true>), dim3 (fgrid_log), dim3 (FK_BLOCK), 0, c->stream, seq, (long) n_bytes, n_ftiles, c->k, mprime, BK, c->d_ctr, \
                             (u32 *) c->slow.p, par, c->fast_mode == 2 ? 1 : 0, LG); \
       else \
       hipLaunchKernelGGL (scan_fast_kernel<WW>, dim3 (fgrid), dim3 (FK_BLOCK), 0, c->stream, seq, (long) n_bytes, n_ftiles, c->k, mprime, BK, c->d_ctr, \
@@ -4532,7 +4574,8 @@ static int scan_device_piece (tjamd_counter *c, const void *d_stream, size_t n_b
     HIPCHK (hipEventRecord (c->ev_pa[i], c->stream));
   }
   if (use_log) {
-    hipLaunchKernelGGL (partition_log_kernel, dim3 ((unsigned) (c->n_cu * PL_WG_PER_CU)), dim3 (PL_BLOCK), 0, c->stream, LG, BK, c->d_ctr, c->k);
+    if (c->W == 1) hipLaunchKernelGGL (partition_log_kernel<1>, dim3 ((unsigned) (c->n_cu * PL_WG_PER_CU)), dim3 (PL_BLOCK), 0, c->stream, LG, BK, c->d_ctr, c->k);
+    else hipLaunchKernelGGL (partition_log_kernel<2>, dim3 ((unsigned) (c->n_cu * PL_WG_PER_CU)), dim3 (PL_BLOCK), 0, c->stream, LG, BK, c->d_ctr, c->k);
     HIPCHK (hipGetLastError ());
   }
   if (mid_events) { HIPCHK (hipEventRecord (c->ev_pb[c->n_piece_ev], c->stream)); c->n_piece_ev++; }
@@ -5105,7 +5148,7 @@ extern "C" double tjamd_last_merge_ms (tjamd_counter *c)
 
 // 1: one-word records go through the record log and partition_log_kernel (k <= 12, the default); 0: every scan kernel
 // partitions its records itself
-extern "C" int tjamd_counter_uses_log (const tjamd_counter *c) { return (c && c->W == 1 && c->log_mode && c->fast_mode) ? 1 : 0; }
+extern "C" int tjamd_counter_uses_log (const tjamd_counter *c) { return (c && c->W <= c->log_mode && c->fast_mode) ? 1 : 0; }
 
 extern "C" double tjamd_last_partition_ms (tjamd_counter *c)
 { // partition_log_kernel behind the last scan launch (k <= 12, record log); 0 when the scan partitioned by itself

@@ -30,6 +30,11 @@ if [ "$MODE" != quick ]; then      # the in-kernel partition of rounds 1-3 (k <=
   echo "SINK=fused: $(tail -1 $O/tests_fused.log)"
   if [ $rc -ne 0 ]; then echo "TESTS FAILED (SINK=fused)"; exit 1; fi
 fi
+if [ "$MODE" != quick ]; then      # two-word records (k 13 ... 28) through the record log as well (default: k <= 12 only)
+  TATAJUBA_AMD_SINK=log timeout -k 10 500 python -m pytest tests -m gpu -x -q > $O/tests_log2.log 2>&1; rc=$?
+  echo "SINK=log: $(tail -1 $O/tests_log2.log)"
+  if [ $rc -ne 0 ]; then echo "TESTS FAILED (SINK=log)"; exit 1; fi
+fi
 if [ "$MODE" = full ]; then
   bash tools/exp_valu.sh > $O/valu.log 2>&1; tail -4 $O/valu.log
 fi
