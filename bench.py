@@ -537,7 +537,7 @@ def main():
         # k <= 28: the scan kernel appends its records to a linear log, partition_log_kernel distributes the log over the hash
         # buckets (its algorithmic bytes: every record read once and written once)
         part_bytes = 2.0 * wbytes * raw
-        out["stages"]["partition"] = {"ms": part_avg, "kernel": "partition_log_kernel", "algorithmic_bytes": part_bytes,
+        out["stages"]["partition"] = {"ms": part_avg, "kernel": "partition_log_kernel<%d>" % (1 if k <= 12 else 2), "algorithmic_bytes": part_bytes,
                                       "algorithmic_GBps": part_bytes / (part_avg * 1e-3) / 1e9, "frac_of_hbm_peak": part_bytes / (part_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "note": "record log -> hash buckets, between the scan and the finalise; TATAJUBA_AMD_SINK=fused makes the scan kernel partition "
                                               "by itself instead (rounds 1-3: a shorter step, the scan kernel at a third of the HBM peak)"}
