@@ -1011,7 +1011,6 @@ struct StageSink
   Buckets B; DevCounters *ctr; int k;
   u32 bound;                                            // upper bound of the records staged (workgroup-uniform)
   u32 cur_j, cur_chunk;                                 // owner thread (tid < TJ_P): the chunk its bucket is being written to
-  u32 blk_p0 = 0;                                       // owner thread, partition_pass<.., EXT>: next position of the run reserved for the bucket
   STAMP_MEMBER
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK >= 4
   u32 exp_cur = 0;
@@ -1116,12 +1115,8 @@ struct StageSink
   }
 
   // FULL: the pass takes exactly the first PS staged records (all RR rounds are full); otherwise all n of them
-  // gsrc: the n records come from global memory (partition_log_kernel: one-word records, nothing staged) instead of the
-  // staging buffer
-  // EXT: the bucket's run was reserved by the caller for several passes at once (owner thread: blk_p0 = its next free
-  // position; partition_log_kernel reserves once per log block)
-  template <bool FULL, bool EXT = false>
-  __device__ __forceinline__ u32 partition_pass (const u32 n, const u64 *__restrict__ gsrc = nullptr)
+  template <bool FULL>
+  __device__ __forceinline__ u32 partition_pass (const u32 n)
   {
     static_assert (!BIG || BLOCK == 2 * TJ_P, "two threads per bucket");
     constexpr int RR = FULL ? PS / BLOCK : R;
@@ -1132,19 +1127,6 @@ struct StageSink
     // never looked at -- and each of the four waves that own buckets works out the whole prefix for itself)
     u64 w[RR][WS], wrem[WS];
     u32 rk[RR], bb[RR], brem = 0;
-    if (gsrc) {
-      if constexpr (W == 1) {
-#pragma unroll
-        for (int r = 0; r < RR; r++) {                  // my records, straight from the log (slots past n: any record of the pass, masked later)
-          const u32 i = (u32) tid + (u32) r * BLOCK;
-          w[r][0] = gsrc[i < n ? i : 0u];
-        }
-#pragma unroll
-        for (int r = 0; r < RR; r++) bb[r] = bucket_of_rec1 ((u32) w[r][0], (u32) (w[r][0] >> 32));
-        PSTAMP (9);
-      }
-    }
-    else
 #pragma unroll
     for (int r = 0; r < RR; r++)                        // my records ...
       if (FULL || (u32) r * BLOCK < n) {
@@ -1187,8 +1169,7 @@ struct StageSink
 #if defined(TJ_EXP_SINK) && TJ_EXP_SINK >= 4            // experiment builds only: a private cursor instead of the global atomic (results are wrong)
       if (cnt) { p0 = exp_cur; exp_cur = (p0 + cnt) & 255u; }
 #else
-      if constexpr (EXT) { p0 = blk_p0; blk_p0 += cnt; }
-      else if (cnt) p0 = atomicAdd (&B.cursors[tid * TJ_CSTRIDE], cnt);
+      if (cnt) p0 = atomicAdd (&B.cursors[tid * TJ_CSTRIDE], cnt);
 #endif
     }
     else if (!FULL && wave == TJ_P / 64) L.offs[tid] = (u32) S + (u32) lane;   // (the spare entries: rank 0 lands on staging slot S + lane)
@@ -1222,7 +1203,7 @@ struct StageSink
       if (cnt) {
 #endif
         const u32 ch = (u32) TJ_CH0 << B.ch_shift;
-        if constexpr (!EXT) bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);      // (EXT: whoever reserved the run has claimed for all of it)
+        bucket_claim_ahead (B, (u32) tid, p0, cnt, ctr);
         const u32 j0 = chunk_of_pos (B, p0), j1 = chunk_of_pos (B, p0 + cnt - 1);
         if (j0 != cur_j) { cur_j = j0; cur_chunk = bucket_chunk_id (B, (u32) tid, j0, true, ctr); }
         if (cur_chunk != TJ_NOCHUNK) a1 = (u64) (size_t) (B.pool + ((u64) cur_chunk * ch + (p0 - j0 * ch)) * W) - (8ull * W) * off;
@@ -2202,10 +2183,10 @@ void scan_fast_kernel (const uint8_t *__restrict__ seq, long n_bytes, long n_fti
   sink.finish ();
 }
 
-// The record log of scan_fast_kernel<1, true> -> the hash buckets.  A workgroup takes log blocks in turn (static stride)
-// and runs StageSink's counting sort on PL_S records at a time: the records come straight from HBM (coalesced) into
-// the staging buffer with their bucket, and partition_pass does the rest -- the same reservation protocol on the same
-// bucket cursors and chunk table as every other producer of raw records.
+// The record log of scan_fast_kernel<W, true> -> the hash buckets.  A workgroup takes log blocks in turn (static stride)
+// and sorts one block per pass by bucket, a counting sort like StageSink's with the records held in registers from HBM
+// to their sorted slot -- the same reservation protocol on the same bucket cursors and chunk table as every other
+// producer of raw records.
 #define PL_BLOCK 512
 #ifndef PL_WG_PER_CU
 #define PL_WG_PER_CU 2
