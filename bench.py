@@ -263,7 +263,7 @@ def main():
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=None,
                     help="a BASELINE.json configuration (SURVEY 8d numbering; 2 = configs[1] = the headline = the default sizes)")
     ap.add_argument("--order-stream", action="store_true", help="the ordering step of a sample's finalise on a stream of its own (tjamd_counter_set_order_stream) instead of the scan's; measured: 0.832 against 0.824 ms per step, so not the default")
-    ap.add_argument("--no-io-stages", action="store_true", help="skip the host-memory and FASTQ-file throughputs (stages.from_host / from_file)")
+    ap.add_argument("--no-io-stages", action="store_true", help="skip the stages measured after the timed region other than the drop-in's (stages.fused_sink, from_host, from_file, from_gzip, from_bgzf)")
     ap.add_argument("--io-reads", type=int, default=2_000_000, help="reads of the sample used for stages.from_host / from_file")
     ap.add_argument("--gz-reads", type=int, default=500_000, help="reads of the sample used for stages.from_gzip / from_bgzf")
     ap.add_argument("--rehearse", action="store_true", help="launch plumbing only, no GPU work (CPU tests)")
@@ -542,6 +542,51 @@ def main():
                                       "note": "record log -> hash buckets, between the scan and the finalise; TATAJUBA_AMD_SINK=fused makes the scan kernel partition "
                                               "by itself instead (rounds 1-3: a shorter step, the scan kernel at a third of the HBM peak)"}
 
+    if rank == 0 and world == 1 and uses_log and "TATAJUBA_AMD_SINK" not in os.environ and not args.no_io_stages:
+        # The other design, on the same box in the same process, outside the timed region: the scan kernel partitions its
+        # records by itself (rounds 1-3) -- a shorter step, a scan kernel at a third of the HBM peak.  Same loop as the timed
+        # one (two counters in turn on the stream), a few steps.
+        os.environ["TATAJUBA_AMD_SINK"] = "fused"
+        try:
+            alt = [tj.Counter(k, device=local) for _ in range(2)]
+        finally:
+            del os.environ["TATAJUBA_AMD_SINK"]
+        for cc in alt:
+            cc.set_stream(stream.cuda_stream)
+        alt_times = []
+
+        def alt_loop(n):
+            prev = None
+            for i in range(n):
+                cc = alt[i % 2]
+                cc.reset()
+                cc.scan_device(dev.data_ptr(), n_bytes, m)
+                cc.finalise_begin(1, args.min_coverage)
+                if prev is not None:
+                    if prev.finalise_end() != 0:
+                        raise SystemExit("finalise failed in the fused-sink stage")
+                    alt_times.append((prev.last_scan_ms(), prev.last_finalise_ms()))
+                prev = cc
+            if prev.finalise_end() != 0:
+                raise SystemExit("finalise failed in the fused-sink stage")
+            alt_times.append((prev.last_scan_ms(), prev.last_finalise_ms()))
+            torch.cuda.synchronize()
+        alt_loop(max(2, min(args.warmup, 5)))
+        alt_times.clear()
+        n_alt = max(2, min(args.steps, 20))
+        t1 = time.perf_counter()
+        alt_loop(n_alt)
+        dta = time.perf_counter() - t1
+        if alt[0].uses_log() or alt[0].n_kept != kept:
+            raise SystemExit("fused-sink stage: not the fused sink, or another histogram")
+        a_scan = float(np.mean([t[0] for t in alt_times]))
+        out["stages"]["fused_sink"] = {"reads_per_s": args.reads * n_alt / dta, "ms_per_step": dta / n_alt * 1e3, "steps": n_alt,
+                                       "scan_ms": a_scan, "scan_frac_of_hbm_peak": scan_bytes / (a_scan * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "finalise_ms": float(np.mean([t[1] for t in alt_times])), "kernel": scan_kernel.replace("true", "false"),
+                                       "note": "TATAJUBA_AMD_SINK=fused, measured after the timed region on the same stream and data: the trade "
+                                               "between the two designs (DESIGN.md 3.1c); `value` and `roofline` are the default's"}
+        for cc in alt:
+            cc.close()
     if rank == 0 and world == 1:
         # what a C caller of the drop-in API gets per sample once its reads are in HBM: the scan, the whole of
         # finalise_hopo_counter's device work AND the copy of the histogram into hc->elem (24-byte records widened to the
