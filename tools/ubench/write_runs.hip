@@ -23,10 +23,12 @@ __global__ __launch_bounds__ (512) void write_linear (u64 *pool, u32 passes)
   for (u32 p = blockIdx.x; p < passes; p += gridDim.x)
     for (int i = threadIdx.x; i < 4096; i += 512) pool[(u64) p * 4096 + i] = ((u64) p << 32) | (u32) i | 1u;
 }
+static u64 g_pool_words;
 template <int R, int STRIDE>
 static void run (const char *what, u64 *pool, u64 region_words, u64 records)
 {
   const u32 passes = (u32) (records / (256 * R));
+  if (255ull * region_words + (u64) passes * STRIDE + R > g_pool_words) { printf ("%s: would write past the pool\n", what); exit (1); }
   hipEvent_t e0, e1; hipEventCreate (&e0); hipEventCreate (&e1);
   float best = 1e9f;
   for (int it = 0; it < 5; it++) {
@@ -40,20 +42,35 @@ static void run (const char *what, u64 *pool, u64 region_words, u64 records)
 }
 int main ()
 {
+  /* 256 frontiers, `sp` words apart; region 0 starts on a 128-byte line (hipMalloc), so a run is line-aligned when both sp and
+     the stride are multiples of 16 words */
   const u64 records = 60000000ull, region_words = records / 256 * 2 + 4096;
   u64 *pool; if (hipMalloc (&pool, 256 * region_words * 8) != hipSuccess) { printf ("alloc failed\n"); return 1; }
   hipMemset (pool, 0, 256 * region_words * 8);
-  run<14, 14> ("runs of 14, back to back", pool, region_words, records);
-  run<16, 16> ("runs of 16 = whole lines", pool, region_words, records);
-  run<14, 16> ("14 of every 16 (aligned, partial)", pool, region_words, records);
-  run<28, 28> ("runs of 28, back to back", pool, region_words, records);
+  g_pool_words = 256 * region_words;
+  const u64 al = 21ull * 12288;                         /* 21 chunks of 96 KB: line-aligned regions */
+  printf ("-- line-aligned regions (%llu words apart)\n", al);
+  run<8, 8> ("runs of 8 = half lines", pool, al, records);
+  run<14, 14> ("runs of 14, back to back", pool, al, records);
+  run<14, 16> ("14 of every 16 (aligned, partial)", pool, al, records);
+  run<16, 16> ("runs of 16 = whole lines", pool, al, records);
+  run<24, 24> ("runs of 24 (64-byte aligned)", pool, al, records);
+  run<28, 32> ("28 of every 32 (aligned, partial)", pool, al, records);
+  run<30, 30> ("runs of 30, back to back", pool, al, records);
+  run<32, 32> ("runs of 32 = two whole lines", pool, al, records);
+  run<40, 40> ("runs of 40 (64-byte aligned)", pool, al, records);
+  run<60, 60> ("runs of 60, back to back", pool, al, records);
+  run<64, 64> ("runs of 64", pool, al, records);
+  run<128, 128> ("runs of 128", pool, al, records);
+  printf ("-- regions that start 112 bytes into a line (%llu words apart)\n", al + 14);
+  run<16, 16> ("runs of 16, every one across two lines", pool, al + 14, records);
+  run<32, 32> ("runs of 32, every one across three lines", pool, al + 14, records);
+  run<64, 64> ("runs of 64, across five lines", pool, al + 14, records);
+  printf ("-- regions 64 bytes into a line (%llu words apart)\n", al + 8);
+  run<32, 32> ("runs of 32, 64-byte aligned", pool, al + 8, records);
+  printf ("-- the first version's regions (%llu words apart: 112 bytes into a line, 968 MB in all)\n", region_words);
   run<32, 32> ("runs of 32", pool, region_words, records);
-  run<60, 60> ("runs of 60, back to back", pool, region_words, records);
-  run<64, 64> ("runs of 64", pool, region_words, records);
-  run<15, 15> ("runs of 15, back to back", pool, region_words, records);
-  run<8, 8> ("runs of 8 = half lines", pool, region_words, records);
-  run<128, 128> ("runs of 128", pool, region_words, records);
-  run<256, 256> ("runs of 256 (2 KB)", pool, region_words, records);
+  run<32, 32> ("runs of 32, regions rounded to lines", pool, region_words + 2, records - 4096);
   {                                                     /* for reference: the same bytes written in a line (every workgroup 32 KB at a time) */
     hipEvent_t e0, e1; hipEventCreate (&e0); hipEventCreate (&e1);
     float best = 1e9f;
