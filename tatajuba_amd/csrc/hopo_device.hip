@@ -19,8 +19,10 @@
 // storage -> aggregation kernels -> radix sort / scans (fallback paths, merge) -> bin kernels -> host layer (tjamd_*).
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>                  // types only: the library is looked up at run time (rccl_api)
+#include <dlfcn.h>
 #include <mutex>
+#include <string>
 #include <new>
 #include <stdint.h>
 #include <stdio.h>
@@ -5704,15 +5706,67 @@ struct tjamd_comm
   double last_ms = -1.0; long last_bytes = 0, last_collectives = 0;
 };
 
-#define NCCLCHK(call, ret) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
-  set_err (TJAMD_ERR_HIP, "%s failed: %s", #call, ncclGetErrorString (r_)); return ret; } } while (0)
+// RCCL is looked up when the first communicator call needs it (dlopen), not when the library is loaded: the one-GPU drop-in
+// has no use for it and must load on a machine without it.  <rccl/rccl.h> gives the types; the seven entry points used:
+struct RcclApi
+{
+  const char *(*GetErrorString) (ncclResult_t);
+  ncclResult_t (*GetUniqueId) (ncclUniqueId *);
+  ncclResult_t (*CommInitRank) (ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy) (ncclComm_t);
+  ncclResult_t (*CommCount) (const ncclComm_t, int *);
+  ncclResult_t (*CommAbort) (ncclComm_t);
+  ncclResult_t (*AllGather) (const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+};
+
+static const RcclApi *rccl_api ()
+{ // TATAJUBA_AMD_RCCL names the library; otherwise the loader's search path, then $ROCM_PATH/lib (default /opt/rocm/lib)
+  static RcclApi api;
+  static bool ok = false;
+  static char why[512] = "";
+  static std::once_flag once;
+  std::call_once (once, [] () {
+    void *h = nullptr;
+    std::string tried;
+    std::vector<std::string> names;
+    if (const char *e = getenv ("TATAJUBA_AMD_RCCL")) names.push_back (e);
+    else {
+      names.push_back ("librccl.so.1"); names.push_back ("librccl.so");
+      const char *rp = getenv ("ROCM_PATH");
+      const std::string root = (rp && *rp) ? rp : "/opt/rocm";
+      names.push_back (root + "/lib/librccl.so.1"); names.push_back (root + "/lib/librccl.so");
+    }
+    for (const std::string &nm : names) {
+      h = dlopen (nm.c_str (), RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+      tried += (tried.empty () ? "" : ", ") + nm;
+    }
+    if (!h) { snprintf (why, sizeof why, "RCCL not found (tried %s): the exchange between processes needs it", tried.c_str ()); return; }
+    struct { const char *name; void **to; } syms[] = {
+      {"ncclGetErrorString", (void **) &api.GetErrorString}, {"ncclGetUniqueId", (void **) &api.GetUniqueId},
+      {"ncclCommInitRank", (void **) &api.CommInitRank}, {"ncclCommDestroy", (void **) &api.CommDestroy},
+      {"ncclCommCount", (void **) &api.CommCount}, {"ncclCommAbort", (void **) &api.CommAbort}, {"ncclAllGather", (void **) &api.AllGather}};
+    for (auto &sy : syms) {
+      *sy.to = dlsym (h, sy.name);
+      if (!*sy.to) { snprintf (why, sizeof why, "RCCL: %s not found in the library that was loaded", sy.name); return; }
+    }
+    ok = true;
+  });
+  if (!ok) { set_err (TJAMD_ERR_HIP, "%s", why); return nullptr; }
+  return &api;
+}
+
+#define NCCLCHK(name, call, ret) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+  set_err (TJAMD_ERR_HIP, "%s failed: %s", name, NC->GetErrorString (r_)); return ret; } } while (0)
 
 extern "C" int tjamd_comm_unique_id (void *id_bytes)
 {
   static_assert (TJAMD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
   if (!id_bytes) return set_err (TJAMD_ERR_ARG, "tjamd_comm_unique_id: null buffer");
+  const RcclApi *NC = rccl_api ();
+  if (!NC) return TJAMD_ERR_HIP;
   ncclUniqueId id;
-  NCCLCHK (ncclGetUniqueId (&id), TJAMD_ERR_HIP);
+  NCCLCHK ("ncclGetUniqueId", NC->GetUniqueId (&id), TJAMD_ERR_HIP);
   memcpy (id_bytes, &id, sizeof id);
   return TJAMD_OK;
 }
@@ -5720,17 +5774,19 @@ extern "C" int tjamd_comm_unique_id (void *id_bytes)
 extern "C" tjamd_comm *tjamd_comm_create (tjamd_counter *c, const void *id_bytes, int rank, int world)
 {
   if (!c || !id_bytes || world < 1 || world > 4096 || rank < 0 || rank >= world) { set_err (TJAMD_ERR_ARG, "tjamd_comm_create: bad arguments"); return NULL; }
+  const RcclApi *NC = rccl_api ();
+  if (!NC) return NULL;
   HIPCHK_NULL (hipSetDevice (c->device));
   tjamd_comm *m = new (std::nothrow) tjamd_comm;
   if (!m) { set_err (TJAMD_ERR_HIP, "out of memory"); return NULL; }
   m->rank = rank; m->world = world; m->device = c->device;
   ncclUniqueId id;
   memcpy (&id, id_bytes, sizeof id);
-  ncclResult_t r = ncclCommInitRank (&m->comm, world, id, rank);
-  if (r != ncclSuccess) { set_err (TJAMD_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString (r)); delete m; return NULL; }
+  ncclResult_t r = NC->CommInitRank (&m->comm, world, id, rank);
+  if (r != ncclSuccess) { set_err (TJAMD_ERR_HIP, "ncclCommInitRank failed: %s", NC->GetErrorString (r)); delete m; return NULL; }
   if (hipHostMalloc ((void **) &m->h_counts, (size_t) world * sizeof (long), hipHostMallocDefault) != hipSuccess ||
       hipEventCreate (&m->ev0) != hipSuccess || hipEventCreate (&m->ev1) != hipSuccess) {
-    set_err (TJAMD_ERR_HIP, "hipHostMalloc / hipEventCreate failed"); (void) ncclCommDestroy (m->comm); delete m; return NULL;
+    set_err (TJAMD_ERR_HIP, "hipHostMalloc / hipEventCreate failed"); (void) NC->CommDestroy (m->comm); delete m; return NULL;
   }
   return m;
 }
@@ -5739,7 +5795,7 @@ extern "C" void tjamd_comm_destroy (tjamd_comm *m)
 {
   if (!m) return;
   (void) hipSetDevice (m->device);
-  if (m->comm) (void) ncclCommDestroy (m->comm);
+  if (m->comm) if (const RcclApi *NC = rccl_api ()) (void) NC->CommDestroy (m->comm);
   release (m->send); release (m->recv); release (m->out); release (m->dcounts);
   if (m->h_counts) (void) hipHostFree (m->h_counts);
   if (m->ev0) (void) hipEventDestroy (m->ev0);
@@ -5759,7 +5815,8 @@ extern "C" int tjamd_comm_world (const tjamd_comm *m) { return m ? m->world : -1
 extern "C" int tjamd_comm_count (const tjamd_comm *m)
 {
   int n = -1;
-  if (!m || !m->comm || ncclCommCount (m->comm, &n) != ncclSuccess) return -1;
+  const RcclApi *NC = (m && m->comm) ? rccl_api () : nullptr;
+  if (!NC || NC->CommCount (m->comm, &n) != ncclSuccess) return -1;
   return n;
 }
 // the last exchange on this communicator: device milliseconds (pack, collective(s), unpack), bytes the data collective
@@ -5838,11 +5895,13 @@ extern "C" long tjamd_allgather_histograms (tjamd_counter *c, tjamd_comm *m, con
   if (c->device != m->device) return -set_err (TJAMD_ERR_ARG, "the communicator was made for device %d, the counter lives on %d", m->device, c->device);
   if (hipSetDevice (c->device) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "hipSetDevice failed");
   if (!m->comm) return -set_err (TJAMD_ERR_STATE, "the communicator was aborted after a failed exchange");
+  const RcclApi *NC = rccl_api ();                      // (there: the communicator was made through it)
+  if (!NC) return -TJAMD_ERR_HIP;
   const int world = m->world;
   const long n_mine = c->n_kept;
   // A rank that gives up between two collectives would leave its peers waiting in theirs for ever: every failure from
   // here on aborts the communicator (ncclCommAbort: the peers' pending and later calls fail instead of hanging).
-  auto give_up = [&] (int code) -> long { if (m->comm) { (void) ncclCommAbort (m->comm); m->comm = nullptr; } return -(long) code; };
+  auto give_up = [&] (int code) -> long { if (m->comm) { (void) NC->CommAbort (m->comm); m->comm = nullptr; } return -(long) code; };
   // (a stream of the communicator's own: the exchange of a finalised sample runs beside the scan of the next one; the
   // caller has seen this counter's finalise end -- tjamd_finalise / tjamd_finalise_end -- so its kept records are complete)
   const hipStream_t st = m->stream ? m->stream : c->stream;
@@ -5855,7 +5914,7 @@ extern "C" long tjamd_allgather_histograms (tjamd_counter *c, tjamd_comm *m, con
   for (int attempt = 0; attempt < 3; attempt++) {
     if (m->cap == 0) {                                  // block size not agreed (first exchange, or the last one overflowed): the counts first
       if (hipMemcpyAsync (d_counts + world, &n_mine, sizeof (long), hipMemcpyHostToDevice, st) != hipSuccess) return give_up (set_err (TJAMD_ERR_HIP, "copy failed"));
-      NCCLCHK (ncclAllGather (d_counts + world, d_counts, sizeof (long), ncclChar, m->comm, st), -TJAMD_ERR_HIP);
+      NCCLCHK ("ncclAllGather (counts)", NC->AllGather (d_counts + world, d_counts, sizeof (long), ncclChar, m->comm, st), -TJAMD_ERR_HIP);
       m->collectives++;
       if (hipMemcpyAsync (m->h_counts, d_counts, (size_t) world * sizeof (long), hipMemcpyDeviceToHost, st) != hipSuccess ||
           hipStreamSynchronize (st) != hipSuccess) return give_up (set_err (TJAMD_ERR_HIP, "exchange of the counts failed: %s", hipGetErrorString (hipGetLastError ())));
@@ -5869,7 +5928,7 @@ extern "C" long tjamd_allgather_histograms (tjamd_counter *c, tjamd_comm *m, con
     if (!rc) rc = ensure (m->out, (size_t) std::max<long> (cap * world, 1) * 24, st);
     if (rc) return give_up (rc);
     hipLaunchKernelGGL (gx_pack_kernel, dim3 (grid_for (3 * std::min (n_mine, cap) + 1)), dim3 (256), 0, st, (const u64 *) c->kept.p, n_mine, cap, (u64 *) m->send.p);
-    NCCLCHK (ncclAllGather (m->send.p, m->recv.p, (size_t) block_words * 8, ncclChar, m->comm, st), -TJAMD_ERR_HIP);
+    NCCLCHK ("ncclAllGather", NC->AllGather (m->send.p, m->recv.p, (size_t) block_words * 8, ncclChar, m->comm, st), -TJAMD_ERR_HIP);
     m->collectives++;
     hipLaunchKernelGGL (gx_unpack_kernel, dim3 (grid_for (3 * cap + 1), (unsigned) std::min (world, 64)), dim3 (256), 0, st,
                         (const u64 *) m->recv.p, block_words, world, cap, (u64 *) m->out.p, d_counts);

@@ -666,11 +666,18 @@ def test_oracle_merge_order_by_hand():
 
 def test_rccl_exchange_entry_points_check_their_arguments_without_a_gpu():
     """the process-per-GPU exchange lives in the C library (ncclAllGather behind tjamd_allgather_histograms): the library
-    links RCCL, exports the entry points and refuses bad arguments before touching a device"""
-    import subprocess
+    exports the entry points, refuses bad arguments before touching a device, and looks RCCL up when a communicator call
+    first needs it -- it is not a load-time dependency of the one-GPU drop-in, and a missing RCCL is said loudly"""
+    import subprocess, sys
     L = tj.lib()
     out = subprocess.run(["readelf", "-d", tj.library_path()], capture_output=True, text=True).stdout
-    assert "librccl.so" in out
+    assert "librccl" not in out and "libamdhip64" in out
+    code = ("import ctypes as C, tatajuba_amd.capi as tj; L = tj.lib(); b = C.create_string_buffer(128); "
+            "rc = L.tjamd_comm_unique_id(b); print(rc, L.tjamd_last_error().decode())")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, TATAJUBA_AMD_RCCL="/nonexistent/librccl.so"))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split()[0] != "0" and "RCCL not found (tried /nonexistent/librccl.so)" in r.stdout
     assert L.tjamd_comm_unique_id(None) != 0 and b"null buffer" in L.tjamd_last_error()
     ident = C.create_string_buffer(128)
     assert L.tjamd_comm_create(None, ident, 0, 1) is None and b"bad arguments" in L.tjamd_last_error()
