@@ -11,7 +11,7 @@ f = glob.glob("$O/**/*counter_collection.csv", recursive=True)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     kn = r["Kernel_Name"].split("(")[0]
-    if "aggregate" in kn or "bin_sort" in kn: agg[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if "aggregate" in kn or "bin_sort" in kn or "partition_log" in kn or "scan_fast" in kn: agg[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kn, a in agg.items():
     print(kn[:30], {k: round(sum(v) / len(v) / 1e6, 2) for k, v in a.items()})
 PY

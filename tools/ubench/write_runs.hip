@@ -18,6 +18,22 @@ __global__ __launch_bounds__ (512) void write_runs (u64 *pool, u64 region_words,
       pool[(u64) b * region_words + (u64) p * STRIDE + o] = ((u64) p << 32) | (u32) i | 1u;
     }
 }
+// the same whole-line runs, every line written in two halves by two store instructions a pass apart (does the L2 put a line
+// together before it leaves?): first the first 64 bytes of every line of the pass, then the second 64 bytes
+template <int R, int STRIDE>
+__global__ __launch_bounds__ (512) void write_runs_split (u64 *pool, u64 region_words, u32 passes)
+{
+  constexpr int N = 256 * R;
+  for (u32 p = blockIdx.x; p < passes; p += gridDim.x)
+    for (int half = 0; half < 2; half++)
+      for (int i = threadIdx.x; i < N / 2; i += 512) {
+        const u32 ii = ((u32) i / 8u) * 16u + (u32) half * 8u + ((u32) i & 7u);      // record ii of the pass: the half-line `half` of line i / 8
+        const u32 b = ii / R, o = ii % R;
+        pool[(u64) b * region_words + (u64) p * STRIDE + o] = ((u64) p << 32) | ii | 1u;
+      }
+}
+template <int R, int STRIDE>
+static void run_split (const char *what, u64 *pool, u64 region_words, u64 records);
 __global__ __launch_bounds__ (512) void write_linear (u64 *pool, u32 passes)
 {
   for (u32 p = blockIdx.x; p < passes; p += gridDim.x)
@@ -34,6 +50,22 @@ static void run (const char *what, u64 *pool, u64 region_words, u64 records)
   for (int it = 0; it < 5; it++) {
     hipEventRecord (e0);
     write_runs<R, STRIDE><<<768, 512>>> (pool, region_words, passes);
+    hipEventRecord (e1); hipEventSynchronize (e1);
+    float ms; hipEventElapsedTime (&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  printf ("%-34s R %3d stride %3d: %.3f ms for %.0f M records = %.0f GB/s of records\n", what, R, STRIDE, best, passes * 256.0 * R / 1e6, passes * 256.0 * R * 8 / best / 1e6);
+}
+template <int R, int STRIDE>
+static void run_split (const char *what, u64 *pool, u64 region_words, u64 records)
+{
+  const u32 passes = (u32) (records / (256 * R));
+  if (255ull * region_words + (u64) passes * STRIDE + R > g_pool_words) { printf ("%s: would write past the pool\n", what); exit (1); }
+  hipEvent_t e0, e1; hipEventCreate (&e0); hipEventCreate (&e1);
+  float best = 1e9f;
+  for (int it = 0; it < 5; it++) {
+    hipEventRecord (e0);
+    write_runs_split<R, STRIDE><<<768, 512>>> (pool, region_words, passes);
     hipEventRecord (e1); hipEventSynchronize (e1);
     float ms; hipEventElapsedTime (&ms, e0, e1);
     if (ms < best) best = ms;
@@ -62,6 +94,8 @@ int main ()
   run<60, 60> ("runs of 60, back to back", pool, al, records);
   run<64, 64> ("runs of 64", pool, al, records);
   run<128, 128> ("runs of 128", pool, al, records);
+  run_split<32, 32> ("runs of 32 on lines, each line in two halves a pass apart", pool, al, records);
+  run_split<16, 16> ("runs of 16 on lines, in two halves", pool, al, records);
   printf ("-- regions that start 112 bytes into a line (%llu words apart)\n", al + 14);
   run<16, 16> ("runs of 16, every one across two lines", pool, al + 14, records);
   run<32, 32> ("runs of 32, every one across three lines", pool, al + 14, records);
