@@ -1486,6 +1486,7 @@ struct LogSink
   u32 bound;
   u32 upto, pend, pend_id;                              // thread 0: last block index with an address in L.blk; a reservation on its way
   u64 scratch;                                          // where lanes without a record write (byte address, 64 words per workgroup)
+  STAMP_MEMBER
 
   __device__ __forceinline__ u64 block_addr (u32 id) const
   {
