@@ -1366,3 +1366,39 @@ def test_scan_windows_batch_matches_single_calls_and_is_fast():
         got = out[:n][sel]
         assert got.tobytes() == np.concatenate(exp).tobytes() and wof[:n][sel].tolist() == expw
         assert (np.diff(wof[:n]) >= 0).all()
+
+
+@pytest.mark.gpu
+def test_bench_line_keeps_its_contract_on_a_small_sample():
+    """bench.py as the driver runs it (one GPU, a child process), on a sample small enough for a test: the one JSON line
+    carries the contract's keys, the roofline and the CPU baseline objects, the partition stage of the default sink and the
+    fused sink measured beside it -- on the same histogram"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {kk: vv for kk, vv in os.environ.items() if kk not in ("TATAJUBA_AMD_SINK", "TATAJUBA_AMD_FAST")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "400000", "--steps", "3", "--warmup", "1", "--cpu-reads", "50000",
+                        "--io-reads", "50000", "--gz-reads", "20000"], capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "reads/s" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - 400000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and abs(roof["achieved"] - roof["algorithmic_bytes"] / (roof["ms"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
+    # (the roofline object is the step's longest stage: on a sample this small the finalise's latency floor, on the headline's the scan)
+    assert (roof["kernel"] == "scan_fast_kernel<1, true>" and roof["algorithmic_bytes"] == 400000 * 151) or roof["kernel"].startswith("finalise")
+    assert d["stages"]["scan"]["kernel"] == "scan_fast_kernel<1, true>" and d["stages"]["scan"]["ms"] > 0 and d["stages"]["finalise"]["ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "reads/s"
+    st = d["stages"]
+    assert st["partition"]["kernel"] == "partition_log_kernel<1>" and st["partition"]["ms"] > 0
+    assert st["partition"]["algorithmic_bytes"] == 16.0 * d["config"]["raw_records_per_gpu"]
+    fs = st["fused_sink"]
+    assert fs["kernel"] == "scan_fast_kernel<1, false>" and fs["reads_per_s"] > 0 and fs["scan_ms"] > 0       # (bench.py itself checks: same kept count)
+    assert st["dropin"]["kept_records"] == d["config"]["kept_records"]
+    for io in ("from_host", "from_file", "from_gzip", "from_bgzf"):
+        assert st[io]["reads_per_s"] > 0, io
