@@ -18,7 +18,9 @@
  *     `levenshtein_distance = max_distance_per_flank + 1` would merge contexts that this restatement keeps apart.  The
  *     restatement follows (a), which is what the function's name and its two cost arguments suggest;
  *     tests/test_cabi.py::test_edit_distance_readings_differ_on_a_shifted_name shows a pair on which (a) and (b) differ, so
- *     that whoever holds biomcmc-lib can settle it with one call.  Product (device, host) and oracle share reading (a).
+ *     that whoever holds biomcmc-lib can settle it with one call.  Product (device, host) and oracle share reading (a) by
+ *     default; reading (b) -- one string may end early, the rest of the other is free -- is there on both sides as well
+ *     (product: TATAJUBA_AMD_EDIT_DISTANCE=free_end; here: orc_set_edit_free_end), for the day the call says (b).
  *   - new_empfreq_from_int_weighted (lengths, n, counts): restated as "distinct values with their summed weights, highest
  *     sum first" (context_histogram.h:42: "h.idx = tract length; h.freq = count"; src/context_histogram.c:282: "histogram,
  *     from high to low count"); the order among equal sums is not stated in the reference: here the larger value first.
@@ -59,12 +61,15 @@ orc_name_from_contexts (const uint64_t *context, int base, int kmer_size, int ne
   return s;
 }
 
-/* UNPINNED (see the header): global edit distance, substitution `cost_sub`, insertion / deletion `cost_indel`. */
+/* UNPINNED (see the header): edit distance, substitution `cost_sub`, insertion / deletion `cost_indel`.  free_end = 0: reading
+ * (a), the global distance.  free_end = 1: reading (b) -- one of the two strings may end early: what is left of the other
+ * costs nothing (the smallest entry of the dynamic programme's last row and last column); the starts are aligned. */
 int
-orc_levenshtein (const char *s1, int n1, const char *s2, int n2, int cost_sub, int cost_indel)
+orc_levenshtein_mode (const char *s1, int n1, const char *s2, int n2, int cost_sub, int cost_indel, int free_end)
 {
-  int x, y, *row = (int *) malloc ((size_t) (n1 + 1) * sizeof (int)), result;
+  int x, y, *row = (int *) malloc ((size_t) (n1 + 1) * sizeof (int)), result, ended;
   for (y = 0; y <= n1; y++) row[y] = y * cost_indel;
+  ended = row[n1];                                      /* s1 used up against the first x characters of s2 */
   for (x = 1; x <= n2; x++) {
     int diag = row[0];
     row[0] = x * cost_indel;
@@ -74,11 +79,26 @@ orc_levenshtein (const char *s1, int n1, const char *s2, int n2, int cost_sub, i
       if (up + cost_indel < best) best = up + cost_indel;
       diag = up; row[y] = best;
     }
+    if (row[n1] < ended) ended = row[n1];
   }
   result = row[n1];
+  if (free_end) {
+    if (ended < result) result = ended;
+    for (y = 0; y <= n1; y++) if (row[y] < result) result = row[y];   /* s2 used up against the first y characters of s1 */
+  }
   free (row);
   return result;
 }
+
+int
+orc_levenshtein (const char *s1, int n1, const char *s2, int n2, int cost_sub, int cost_indel)
+{
+  return orc_levenshtein_mode (s1, n1, s2, n2, cost_sub, cost_indel, 0);
+}
+
+/* which reading orc_genomic_context_list's retry uses (tests set it next to the product's TATAJUBA_AMD_EDIT_DISTANCE) */
+static int orc_edit_free_end = 0;
+void orc_set_edit_free_end (int on) { orc_edit_free_end = on ? 1 : 0; }
 
 /* the part of struct context_histogram_struct (src/context_histogram.h:18-43) that exists without the aligner */
 typedef struct
@@ -192,7 +212,7 @@ orc_genomic_context_list (const hopo_element *elem, long n, int kmer_size, int m
       else {
         if (distance < ORC_CH_MAX_DIST) {               /* :255-256 try again, now using indels */
           int len = (int) strlen (ch->name);            /* :21-22 */
-          distance = orc_levenshtein (ch->name, len, histname, len, 1, 1);
+          distance = orc_levenshtein_mode (ch->name, len, histname, len, 1, 1, orc_edit_free_end);
         }
         if (distance < levenshtein_distance) {          /* :258-261 */
           orc_ch_add (ch, &elem[i], i, histname, idx_match);

@@ -55,6 +55,8 @@ typedef struct
 } orc_group;
 char *orc_name_from_contexts (const uint64_t *context, int base, int kmer_size, int neg_strand);
 int orc_levenshtein (const char *s1, int n1, const char *s2, int n2, int cost_sub, int cost_indel);
+int orc_levenshtein_mode (const char *s1, int n1, const char *s2, int n2, int cost_sub, int cost_indel, int free_end);
+void orc_set_edit_free_end (int on);
 long orc_genomic_context_list (const hopo_element *elem, long n, int kmer_size, int max_distance_per_flank, int levenshtein_distance,
                                int min_tract_size, int genome_coverage, int *group_of, int *join_type, orc_group *g, int *hist_len, int *hist_freq, uint64_t *contexts);
 long orc_merge_samples (const uint64_t *rec3, const long *counts_in, int n_samples, int *cat_sample, int *cat_index, uint64_t *keys3, int *counts);

@@ -69,6 +69,9 @@ def lib():
         L.orc_tract_ids.restype = C.c_long; L.orc_tract_ids.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
         L.orc_name_from_contexts.restype = C.c_void_p; L.orc_name_from_contexts.argtypes = [U64P, C.c_int, C.c_int, C.c_int]
         L.orc_levenshtein.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.orc_levenshtein_mode.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_set_edit_free_end.argtypes = [C.c_int]
+        L.orc_set_edit_free_end.restype = None
         L.orc_genomic_context_list.restype = C.c_long
         L.orc_genomic_context_list.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
         L.orc_merge_samples.restype = C.c_long
@@ -183,10 +186,15 @@ ORC_GROUP_DTYPE = np.dtype([("first", "<i4"), ("n_elem", "<i4"), ("n_context", "
 assert ORC_GROUP_DTYPE.itemsize == 64
 
 
-def levenshtein(a, b, cost_sub=1, cost_indel=1):
-    """UNPINNED restatement of biomcmc_levenshtein_distance (see context_oracle.c)"""
+def levenshtein(a, b, cost_sub=1, cost_indel=1, free_end=False):
+    """UNPINNED restatement of biomcmc_levenshtein_distance (see context_oracle.c); free_end: its second reading"""
     a, b = (x.encode("latin-1") if isinstance(x, str) else x for x in (a, b))
-    return lib().orc_levenshtein(a, len(a), b, len(b), cost_sub, cost_indel)
+    return lib().orc_levenshtein_mode(a, len(a), b, len(b), cost_sub, cost_indel, int(bool(free_end)))
+
+
+def set_edit_free_end(on):
+    """which reading genomic_context_list's retry uses (default: the global distance)"""
+    lib().orc_set_edit_free_end(int(bool(on)))
 
 
 def genomic_context_list(elems, kmer_size, max_distance_per_flank, levenshtein_distance, min_tract_size, coverage=0):

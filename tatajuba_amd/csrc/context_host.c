@@ -20,13 +20,24 @@ ctx_fatal (const char *msg)
   exit (EXIT_FAILURE);
 }
 
-/* unit-cost global edit distance (stands for biomcmc_levenshtein_distance (s1, n, s2, n, 1, 1, true): UNPINNED) */
+/* Unit-cost edit distance: stands for biomcmc_levenshtein_distance (s1, n, s2, n, 1, 1, true), whose source is not in the
+ * reference tree (UNPINNED).  Default: the global distance.  TATAJUBA_AMD_EDIT_DISTANCE=free_end: the other reading of
+ * that last argument -- one of the strings may end early and the rest of the other costs nothing (oracle/context_oracle.c). */
+static int
+ctx_edit_free_end (void)
+{
+  static int mode = -1;
+  if (mode < 0) { const char *e = getenv ("TATAJUBA_AMD_EDIT_DISTANCE"); mode = (e && !strcmp (e, "free_end")) ? 1 : 0; }
+  return mode;
+}
+
 static int
 ctx_edit_distance (const char *s1, int n1, const char *s2, int n2)
 {
-  int x, y, result, *row = (int *) malloc ((size_t) (n1 + 1) * sizeof (int));
+  int x, y, result, early, *row = (int *) malloc ((size_t) (n1 + 1) * sizeof (int));
   if (!row) ctx_fatal ("out of memory");
   for (y = 0; y <= n1; y++) row[y] = y;
+  early = row[n1];                                      /* s1 used up before s2 */
   for (x = 1; x <= n2; x++) {
     int diag = row[0];
     row[0] = x;
@@ -37,8 +48,13 @@ ctx_edit_distance (const char *s1, int n1, const char *s2, int n2)
       if (up + 1 < best) best = up + 1;
       diag = up; row[y] = best;
     }
+    if (row[n1] < early) early = row[n1];
   }
   result = row[n1];
+  if (ctx_edit_free_end ()) {
+    if (early < result) result = early;
+    for (y = 0; y <= n1; y++) if (row[y] < result) result = row[y];   /* s2 used up before s1 */
+  }
   free (row);
   return result;
 }

@@ -5279,13 +5279,14 @@ __device__ __forceinline__ u32 name_symbol (u64 c0, u64 c1, u32 base, int k, int
   return (u32) (c1 >> (2 * (t - k - 3))) & 3u;
 }
 
-__device__ int name_edit_distance (const u64 *__restrict__ kept, long a, long b, int k)
+__device__ int name_edit_distance (const u64 *__restrict__ kept, long a, long b, int k, int free_end)
 {
   const u64 a0 = kept[3 * a], a1 = kept[3 * a + 1], b0 = kept[3 * b], b1 = kept[3 * b + 1];
   const u32 ab = (u32) (kept[3 * a + 2] & 3ull), bb = (u32) (kept[3 * b + 2] & 3ull);
   const int n = 2 * k + 3;
   unsigned char row[2 * 32 + 4];
   for (int y = 0; y <= n; y++) row[y] = (unsigned char) y;
+  int early = n;                                        // (free_end) a used up before b
   for (int x = 1; x <= n; x++) {
     const u32 sb = name_symbol (b0, b1, bb, k, x - 1);
     int diag = row[0];
@@ -5296,8 +5297,14 @@ __device__ int name_edit_distance (const u64 *__restrict__ kept, long a, long b,
       best = min (best, min ((int) row[y - 1], up) + 1);
       diag = up; row[y] = (unsigned char) best;
     }
+    early = min (early, (int) row[n]);
   }
-  return row[n];
+  int result = row[n];
+  if (free_end) {                                       // the other reading of the absent function's last argument: one name may end early
+    result = min (result, early);
+    for (int y = 0; y <= n; y++) result = min (result, (int) row[y]);
+  }
+  return result;
 }
 
 // join types on the device: 0 opened its histogram, 1 joined within the flank distance and met its own context in the
@@ -5306,7 +5313,7 @@ __device__ int name_edit_distance (const u64 *__restrict__ kept, long a, long b,
 #define GJ_ADDS_CONTEXT(t) ((t) != 1)
 
 // (2): elements that open a group in the grouping without the retry, tested against the name of the group before them
-__global__ void group_speculate_kernel (const u64 *__restrict__ kept, long n, int k, int lev, const u32 *__restrict__ head,
+__global__ void group_speculate_kernel (const u64 *__restrict__ kept, long n, int k, int lev, int free_end, const u32 *__restrict__ head,
                                         u32 *__restrict__ cand, int *__restrict__ jt, u32 *__restrict__ n_cand)
 {
   for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < n; i += (long) gridDim.x * blockDim.x) {
@@ -5320,7 +5327,7 @@ __global__ void group_speculate_kernel (const u64 *__restrict__ kept, long n, in
       long mode = ph;
       int mc = meta_count (kept[3 * ph + 2]);
       for (long j = ph + 1; j < i; j++) { const int cj = meta_count (kept[3 * j + 2]); if (cj > mc) { mc = cj; mode = j; } }
-      if (name_edit_distance (kept, mode, i, k) < lev) { c = 1u; atomicAdd (n_cand, 1u); }
+      if (name_edit_distance (kept, mode, i, k, free_end) < lev) { c = 1u; atomicAdd (n_cand, 1u); }
     }
     cand[i] = c;
   }
@@ -5333,7 +5340,7 @@ __global__ void group_speculate_kernel (const u64 *__restrict__ kept, long n, in
 // distance 0 at an identical one (whatever comes after it), otherwise the largest distance met.
 #define GR_CHUNK 4096
 __global__ __launch_bounds__ (256)
-void group_repair_kernel (const u64 *__restrict__ kept, long n, int k, int maxd, int lev,
+void group_repair_kernel (const u64 *__restrict__ kept, long n, int k, int maxd, int lev, int free_end,
                           u32 *__restrict__ head, const u32 *__restrict__ cand, int *__restrict__ jt)
 {
   __shared__ long s_pos, s_min;
@@ -5374,7 +5381,7 @@ void group_repair_kernel (const u64 *__restrict__ kept, long n, int k, int maxd,
           }
           int type = 0;
           if (!fail && (matched ? 0 : this_max) < maxd) type = matched ? 1 : 5;
-          else if (name_edit_distance (kept, mode, i, k) < lev) type = 2;  // the indel retry
+          else if (name_edit_distance (kept, mode, i, k, free_end) < lev) type = 2;  // the indel retry
           if (type) {
             head[i] = 0u; jt[i] = type;
             const int ci = meta_count (kept[3 * i + 2]);
@@ -5461,12 +5468,15 @@ extern "C" long tjamd_context_histograms (tjamd_counter *c, int max_distance_per
   hipLaunchKernelGGL (group_back_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, kept, n, max_distance_per_flank, (int *) c->headpos.p);
   hipLaunchKernelGGL (group_resolve_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, (const int *) c->headpos.p, n, (u32 *) c->flags.p);
   if (hipMemsetAsync (n_cand, 0, 4, c->stream) != hipSuccess) return -set_err (TJAMD_ERR_HIP, "memset failed");
-  hipLaunchKernelGGL (group_speculate_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, kept, n, c->k, levenshtein_distance,
+  // (which reading of the absent edit distance's last argument: looked up per call -- tests switch it)
+  const char *ed = getenv ("TATAJUBA_AMD_EDIT_DISTANCE");
+  const int free_end = (ed && !strcmp (ed, "free_end")) ? 1 : 0;
+  hipLaunchKernelGGL (group_speculate_kernel, dim3 (grid_for (n)), dim3 (256), 0, c->stream, kept, n, c->k, levenshtein_distance, free_end,
                       (const u32 *) c->flags.p, (u32 *) c->keep.p, (int *) c->grp_jt.p, n_cand);
   u32 nc = 0;
   if (hipMemcpyAsync (&nc, n_cand, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize (c->stream) != hipSuccess)
     return -set_err (TJAMD_ERR_HIP, "grouping failed: %s", hipGetErrorString (hipGetLastError ()));
-  if (nc) hipLaunchKernelGGL (group_repair_kernel, dim3 (1), dim3 (256), 0, c->stream, kept, n, c->k, max_distance_per_flank, levenshtein_distance,
+  if (nc) hipLaunchKernelGGL (group_repair_kernel, dim3 (1), dim3 (256), 0, c->stream, kept, n, c->k, max_distance_per_flank, levenshtein_distance, free_end,
                               (u32 *) c->flags.p, (const u32 *) c->keep.p, (int *) c->grp_jt.p);
   rc = exclusive_scan (c, (const u32 *) c->flags.p, (u32 *) c->outpos.p, n, total, (u32 *) c->scan_tmp.p, scan_tmp_words (n));
   if (rc) return -rc;

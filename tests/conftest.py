@@ -24,3 +24,13 @@ def known_answers():
     import json
     with open(os.path.join(GOLDEN, "known_answers.json")) as fh:
         return json.load(fh)
+
+
+@pytest.fixture(autouse=True)
+def _oracle_reading_of_the_edit_distance_back_to_default():
+    """a test may switch the oracle's grouping to the second reading of the absent edit distance (orc.set_edit_free_end):
+    whatever happens in it, the next test starts from the default"""
+    yield
+    orc = sys.modules.get("oracle.orc")
+    if orc is not None and getattr(orc, "_LIB", None) is not None:
+        orc.set_edit_free_end(0)

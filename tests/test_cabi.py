@@ -699,15 +699,21 @@ def test_edit_distance_readings_differ_on_a_shifted_name():
     a, b = "ACGTACGTAC.A.TTGACCATGG", "ACGTACGTAC.A.TGACCATGGA"       # right flank shifted left by one base
     assert orc.levenshtein(a, b) == 2                                 # global: one deletion + one insertion
 
-    def free_end_gaps(x, y):                                          # reading (b), for contrast only: never used by the product
-        prev = [0] * (len(y) + 1)
-        for i in range(1, len(x) + 1):
-            cur = [0] + [0] * len(y)
-            for j in range(1, len(y) + 1):
-                cur[j] = min(prev[j - 1] + (x[i - 1] != y[j - 1]), prev[j] + 1, cur[j - 1] + 1)
-            prev = cur
-        return min(prev)
-    assert free_end_gaps(a, b) < orc.levenshtein(a, b)
+    def free_end(x, y):                                               # reading (b) by hand: one string may end early, the rest of the other is free
+        d = [[0] * (len(y) + 1) for _ in range(len(x) + 1)]
+        for i in range(len(x) + 1):
+            for j in range(len(y) + 1):
+                if i == 0 or j == 0:
+                    d[i][j] = i + j
+                else:
+                    d[i][j] = min(d[i - 1][j - 1] + (x[i - 1] != y[j - 1]), d[i - 1][j] + 1, d[i][j - 1] + 1)
+        return min(min(d[len(x)]), min(row[len(y)] for row in d))
+    assert free_end(a, b) == 1 == orc.levenshtein(a, b, free_end=True)
+    rng = random.Random(77)
+    for _ in range(300):                                              # the oracle's second reading against the by-hand table
+        x = "".join(rng.choice("ACGT.") for _ in range(rng.randrange(0, 14)))
+        y = "".join(rng.choice("ACGT.") for _ in range(rng.randrange(0, 14)))
+        assert orc.levenshtein(x, y, free_end=True) == free_end(x, y) <= orc.levenshtein(x, y)
     # the host function a caller links (include/tatajuba_context.h) follows the same reading as the oracle
     import ctypes as C
     L = tj.lib()
@@ -717,3 +723,11 @@ def test_edit_distance_readings_differ_on_a_shifted_name():
     L.indel_distance_between_context_histogram_and_hopo_context.restype = C.c_int
     L.indel_distance_between_context_histogram_and_hopo_context.argtypes = [C.c_void_p, C.c_char_p]
     assert L.indel_distance_between_context_histogram_and_hopo_context(C.byref(ch), b.encode()) == 2
+    # ... and the other reading when asked for (TATAJUBA_AMD_EDIT_DISTANCE=free_end, read once per process: a child)
+    import subprocess, sys
+    code = ("import ctypes as C, tatajuba_amd as tj; from tatajuba_amd.capi import ContextHistogramStruct; L = tj.lib(); ch = ContextHistogramStruct(); "
+            f"ch.name = {a.encode()!r}; L.indel_distance_between_context_histogram_and_hopo_context.restype = C.c_int; "
+            "L.indel_distance_between_context_histogram_and_hopo_context.argtypes = [C.c_void_p, C.c_char_p]; "
+            f"print(L.indel_distance_between_context_histogram_and_hopo_context(C.byref(ch), {b.encode()!r}))")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, TATAJUBA_AMD_EDIT_DISTANCE="free_end"))
+    assert r.returncode == 0 and r.stdout.split()[-1] == "1", r.stderr

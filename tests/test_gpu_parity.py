@@ -986,14 +986,21 @@ def _hist_mask(groups, n):
     return m
 
 
-@pytest.mark.parametrize("k,maxd,lev", [(10, 1, 2), (10, 1, 3), (10, 2, 3), (10, 0, 2), (10, 2, 0), (25, 2, 4), (32, 1, 3), (4, 1, 2)])
-def test_context_histograms_with_indel_retry_match_the_oracle(k, maxd, lev):
+@pytest.mark.parametrize("k,maxd,lev,free_end", [(10, 1, 2, 0), (10, 1, 3, 0), (10, 2, 3, 0), (10, 0, 2, 0), (10, 2, 0, 0), (25, 2, 4, 0), (32, 1, 3, 0), (4, 1, 2, 0),
+                                                  (10, 1, 2, 1), (10, 2, 3, 1), (25, 2, 4, 1)])
+def test_context_histograms_with_indel_retry_match_the_oracle(k, maxd, lev, free_end, monkeypatch):
     """tjamd_context_histograms == the oracle's restatement of new_genomic_context_list (src/context_histogram.c:245-270: flank
     distance :25-48, then the retry with the edit distance between the names :19-23,255-261, bookkeeping :181-222, length
     histograms :278-286) on a sample whose families differ by substitutions AND by one-base indels in the right flank (the
     left flank's first bases vary as well: in context order those stay neighbours).  UNPINNED pieces, same on both sides:
-    the edit distance (biomcmc_levenshtein_distance is absent from the reference tree: unit-cost global edit distance) and
-    the order of equal counts in a length histogram."""
+    the edit distance (biomcmc_levenshtein_distance is absent from the reference tree: unit-cost global edit distance, or --
+    free_end, TATAJUBA_AMD_EDIT_DISTANCE=free_end -- the other reading of its last argument) and the order of equal counts
+    in a length histogram."""
+    if free_end:
+        monkeypatch.setenv("TATAJUBA_AMD_EDIT_DISTANCE", "free_end")
+    else:
+        monkeypatch.delenv("TATAJUBA_AMD_EDIT_DISTANCE", raising=False)
+    orc.set_edit_free_end(free_end)
     rng = random.Random(1000 * k + 10 * maxd + lev)
     mask = (1 << (2 * k)) - 1
     e = []
@@ -1028,6 +1035,9 @@ def test_context_histograms_with_indel_retry_match_the_oracle(k, maxd, lev):
     kept = c.download_kept()
     got = c.context_histograms(maxd, lev)
     want = orc.genomic_context_list(kept, k, maxd, lev, 3)
+    if free_end:                                                                      # the second reading takes in more than the first
+        orc.set_edit_free_end(0)
+        assert (want["join_type"] == 2).sum() > (orc.genomic_context_list(kept, k, maxd, lev, 3)["join_type"] == 2).sum()
     g, w = got["groups"], want["groups"]
     assert len(g) == len(w) and (got["group_of"] == want["group_of"]).all() and (got["join_type"] == want["join_type"]).all()
     for f in ("first", "n_elem", "n_context", "mode", "indel", "n_len", "modal_len", "modal_freq", "integral"):
