@@ -12,8 +12,9 @@
  * other field, not layout-compatible).
  *
  * Two pieces stand for biomcmc-lib code that is absent from the reference tree (UNPINNED, see oracle/context_oracle.c):
- * the edit distance behind indel_distance_between_context_histogram_and_hopo_context and the order of equal counts
- * inside an empfreq. */
+ * the edit distance behind indel_distance_between_context_histogram_and_hopo_context (the global unit-cost distance; with
+ * TATAJUBA_AMD_EDIT_DISTANCE=free_end the other reading of biomcmc_levenshtein_distance's last argument: one string may
+ * end early) and the order of equal counts inside an empfreq. */
 #ifndef TATAJUBA_AMD_CONTEXT_H
 #define TATAJUBA_AMD_CONTEXT_H
 
