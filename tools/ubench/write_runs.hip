@@ -32,6 +32,17 @@ __global__ __launch_bounds__ (512) void write_runs_split (u64 *pool, u64 region_
         pool[(u64) b * region_words + (u64) p * STRIDE + o] = ((u64) p << 32) | ii | 1u;
       }
 }
+// for reference: the same records read in a line and written in a line (what a partition moves, without the partition)
+__global__ __launch_bounds__ (512) void copy_linear (const u64 *__restrict__ src, u64 *__restrict__ dst, u32 passes)
+{
+  for (u32 p = blockIdx.x; p < passes; p += gridDim.x) {
+    u64 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = src[(u64) p * 4096 + threadIdx.x + 512 * i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) dst[(u64) p * 4096 + threadIdx.x + 512 * i] = v[i] | 1u;
+  }
+}
 template <int R, int STRIDE>
 static void run_split (const char *what, u64 *pool, u64 region_words, u64 records);
 __global__ __launch_bounds__ (512) void write_linear (u64 *pool, u32 passes)
@@ -116,6 +127,20 @@ int main ()
       if (ms < best) best = ms;
     }
     printf ("%-34s               : %.3f ms for %.0f M records = %.0f GB/s of records\n", "in a line, 32 KB per workgroup", best, records / 4096 * 4096 / 1e6, records / 4096 * 4096.0 * 8 / best / 1e6);
+  }
+  {                                                     /* read in a line + written in a line: the first half of the pool to the second half (60 M records each way fit: 2 x 480 MB of 968) */
+    hipEvent_t e0, e1; hipEventCreate (&e0); hipEventCreate (&e1);
+    const u32 passes = (u32) (records / 4096);
+    if ((u64) passes * 4096 * 2 > g_pool_words) { printf ("copy: pool too small\n"); return 1; }
+    float best = 1e9f;
+    for (int it = 0; it < 5; it++) {
+      hipEventRecord (e0);
+      copy_linear<<<768, 512>>> (pool, pool + (u64) passes * 4096, passes);
+      hipEventRecord (e1); hipEventSynchronize (e1);
+      float ms; hipEventElapsedTime (&ms, e0, e1);
+      if (ms < best) best = ms;
+    }
+    printf ("%-34s               : %.3f ms for %.0f M records = %.0f GB/s read + as much written\n", "copied in a line", best, passes * 4096.0 / 1e6, passes * 4096.0 * 8 / best / 1e6);
   }
   return 0;
 }
