@@ -2525,6 +2525,24 @@ __device__ __forceinline__ void plan_tail (FinCounts *fin, int k, long cap, FinP
   }
 }
 
+// The t-th batch a workgroup hands to its waves: the bucket is read FROM ITS END.  The order of the records does not matter to
+// a hash aggregation, and what a bucket received last is what the 256 MB memory-side cache may still hold when the
+// aggregation starts right behind the kernel that filled it: behind partition_log_kernel the waves' wait for their loads
+// fell by more than half and the kernel from 0.160 to 0.137 ms (the time it takes behind the fused scan kernel).
+// Returns a position >= n when the bucket is used up.
+#ifndef AG_FROM_END
+#define AG_FROM_END 1
+#endif
+__device__ __forceinline__ u32 batch_start (u32 t, u32 n, u32 batch)
+{
+#if AG_FROM_END
+  const u32 nb = (n + batch - 1u) / batch;
+  return t < nb ? (nb - 1u - t) * batch : n;
+#else
+  return t * batch;
+#endif
+}
+
 struct Agg1Lds
 {
   u64 key[AG1_S];                       // record without its strand flag (never 0: the base next to an A tract is not A)
@@ -2596,7 +2614,7 @@ void aggregate1_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     auto next_batch = [&] () {
       u32 b = 0;
       if (lane == 0) b = atomicAdd (&L.next_batch, 1u);
-      return (u32) __builtin_amdgcn_readfirstlane ((int) b) * (64u * AG1_R);
+      return batch_start ((u32) __builtin_amdgcn_readfirstlane ((int) b), n, 64u * AG1_R);
     };
     u32 b_next = next_batch ();
     fetch (b_next);
@@ -2838,7 +2856,7 @@ void aggregate2_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     auto next_batch = [&] () {
       u32 b = 0;
       if (lane == 0) b = atomicAdd (&L.next_batch, 1u);
-      return (u32) __builtin_amdgcn_readfirstlane ((int) b) * (64u * AG2_R);
+      return batch_start ((u32) __builtin_amdgcn_readfirstlane ((int) b), n, 64u * AG2_R);
     };
     u32 b_next = next_batch ();
     fetch (b_next);
@@ -3075,7 +3093,7 @@ void aggregate4_kernel (Buckets BK, u64 *ovf, int k, int remove_biased, u64 *__r
     auto next_batch = [&] () {
       u32 b = 0;
       if (lane == 0) b = atomicAdd (&L.next_batch, 1u);
-      return (u32) __builtin_amdgcn_readfirstlane ((int) b) * (64u * AG4_R);
+      return batch_start ((u32) __builtin_amdgcn_readfirstlane ((int) b), n, 64u * AG4_R);
     };
     u32 b_next = next_batch ();
     fetch (b_next);
